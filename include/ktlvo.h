@@ -1,0 +1,200 @@
+/*
+ * ktlvo.h -- C ABI of libktlvo_hip.so: the MI355X (gfx950) implementation of the ktl_vo
+ * feature-tracking hot path (scofield1991/slam, src/ktl_vo).
+ *
+ * The reference has no FFI or plugin layer for this path; it reaches the arithmetic through
+ * C++ free functions and OpenCV calls.  Each entry point below names the reference interface
+ * (file:line under src/ktl_vo/src/) it stands behind.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns KTLVO_OK (0) or a negative ktlvo_status; nothing throws;
+ *   - the caller owns every host buffer; device memory is owned by the context;
+ *   - *_dev variants take DEVICE pointers, enqueue on the context's stream and return
+ *     without synchronising; the others take HOST pointers and return after the result
+ *     has been copied back;
+ *   - a ktlvo_ctx is not thread-safe (the reference's callbacks are serialised by
+ *     ros::spin(), featureTracking.cpp:727); use one context per GPU and host thread;
+ *   - point lists are interleaved float (x,y) like std::vector<cv::Point2f>;
+ *   - empty inputs (n == 0) are legal everywhere and return KTLVO_OK.
+ */
+#ifndef KTLVO_H
+#define KTLVO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    KTLVO_OK = 0,
+    KTLVO_ERR_INVALID = -1,     /* bad argument (null pointer, size mismatch, bad slot) */
+    KTLVO_ERR_UNSUPPORTED = -2, /* parameter value the HIP path does not implement */
+    KTLVO_ERR_HIP = -3,         /* a HIP runtime call failed; see ktlvo_last_error() */
+    KTLVO_ERR_CAPACITY = -4,    /* more points / ROIs / hypotheses than the context was sized for */
+    KTLVO_ERR_STATE = -5,       /* call order (e.g. tracking a slot whose pyramid was not built) */
+    KTLVO_ERR_NOMEM = -6
+} ktlvo_status;
+
+typedef struct ktlvo_ctx ktlvo_ctx;
+
+/* Run-time form of the reference's compile-time constants. */
+typedef struct {
+    int width, height;             /* cameraParameters.h:16-17 (1242 x 375) */
+    double fx, fy, cx, cy;         /* cameraParameters.h:19-22 */
+    double bf;                     /* cameraParameters.h:27 */
+    int num_slots;                 /* device image slots (each holds one padded pyramid) */
+    int max_level;                 /* featureTracking.cpp:81  lktPyramid = 4 (levels 0..4) */
+    int win;                       /* featureTracking.cpp:80  winSize = 21 */
+    int max_points;                /* capacity of one point list */
+    int max_batch_pairs;           /* capacity of ktlvo_pyrlk_batch_dev */
+    int x_subregions, y_subregions;/* featureTracking.cpp:69-70 (20, 8) */
+    int max_per_subregion;         /* featureTracking.cpp:68 (100) */
+    int x_boundary, y_boundary;    /* featureTracking.cpp:74-75 (30, 30) */
+    double max_track_dis;          /* featureTracking.cpp:79 (100) */
+    int anms_keep;                 /* featureTracking.cpp:433 (1000) */
+    int keyframe_min_tracked;      /* featureTracking.cpp:406 (300) */
+    int ransac_iters;              /* visualOdometry.cpp:125 (300) */
+    float ransac_reproj;           /* visualOdometry.cpp:126 (0.1f) */
+    double ransac_conf;            /* visualOdometry.cpp:127 ((double)0.99f) */
+    int max_hypotheses;            /* capacity of ktlvo_ransac_score */
+} ktlvo_config;
+
+/* cv::calcOpticalFlowPyrLK arguments as passed at featureTracking.cpp:205-209. */
+typedef struct {
+    int win;            /* 21 (the only window the HIP kernel is specialised for) */
+    int max_level;      /* 4 */
+    int max_count;      /* TermCriteria count, 30 */
+    double epsilon;     /* TermCriteria epsilon, 0.01 (squared internally, as OpenCV does) */
+    double min_eig_thr; /* minEigThreshold default 1e-4 */
+} ktlvo_lk_params;
+
+/* cv::GFTTDetector::create(100, 0.01, 10, 3, true, 0.0), featureTracking.cpp:103. */
+typedef struct {
+    int max_corners;    /* 100 per ROI */
+    double quality;     /* 0.01 */
+    double min_dist;    /* 10 */
+    int block_size;     /* 3 (only value implemented) */
+    int use_harris;     /* 1 */
+    double harris_k;    /* 0.0 */
+} ktlvo_gftt_params;
+
+typedef struct { int x, y, w, h; } ktlvo_roi;                                   /* cv::Rect */
+typedef struct { float u, v; int ind; } ktlvo_image_point;                      /* pointDefinition.h:18-21 */
+typedef struct { float u, v, depth; int label, ind, newKeyFrame; } ktlvo_depth_point; /* pointDefinition.h:28-34 */
+
+/* Kernel identifiers for ktlvo_profile_get. */
+enum { KTLVO_K_PYRDOWN = 0, KTLVO_K_PYRLK = 1, KTLVO_K_CORNER = 2, KTLVO_K_RANSAC = 3, KTLVO_K_COUNT = 4 };
+
+/* ---- life cycle ----------------------------------------------------------------------- */
+/* Fills the reference's constants (cameraParameters.h:16-27, featureTracking.cpp:68-81,
+ * visualOdometry.cpp:122-127) and default capacities. */
+int ktlvo_default_config(ktlvo_config *cfg);
+/* Replaces the reference's process globals (featureTracking.cpp:24-123) with one object. */
+ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id);
+void ktlvo_destroy(ktlvo_ctx *ctx);
+/* Use the caller's hipStream_t (NULL = the context's own stream) for all later work. */
+int ktlvo_set_stream(ktlvo_ctx *ctx, void *hip_stream);
+int ktlvo_sync(ktlvo_ctx *ctx);
+const char *ktlvo_strerror(int status);
+const char *ktlvo_last_error(const ktlvo_ctx *ctx); /* text of the last HIP failure */
+
+/* ---- images and pyramids ---------------------------------------------------------------- */
+/* cv_bridge::toCvCopy(msg, MONO8) -> Mat (featureTracking.cpp:346-365): host image into a slot. */
+int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride);
+/* Same from a device buffer (frame already resident in HBM). */
+int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride);
+/* cv::buildOpticalFlowPyramid as called inside calcOpticalFlowPyrLK (featureTracking.cpp:205):
+ * pyrDown per level, reflect-101 border of `win` pixels.  Level count follows OpenCV's rule
+ * (stop when the next level is not larger than the window). */
+int ktlvo_build_pyramid(ktlvo_ctx *ctx, int slot, int max_level, int win);
+/* The same for several slots in one set of launches. */
+int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slots, int max_level, int win);
+/* Test hooks: copy one level (tightly packed w*h) / its Scharr derivative (calcSharrDeriv,
+ * interleaved int16 dx,dy) back to the host. */
+int ktlvo_pyramid_levels(ktlvo_ctx *ctx, int slot, int *max_level_built);
+int ktlvo_download_level(ktlvo_ctx *ctx, int slot, int level, uint8_t *dst, int *w, int *h);
+int ktlvo_download_scharr(ktlvo_ctx *ctx, int slot, int level, int16_t *dst);
+
+/* ---- pyramidal Lucas-Kanade ------------------------------------------------------------- */
+/* cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(21,21), 4,
+ * TermCriteria(COUNT|EPS,30,0.01), 0): featureTracking.cpp:205-209, 214-218, 457-479.
+ * Both slots must hold built pyramids. */
+int ktlvo_pyrlk(ktlvo_ctx *ctx, int prev_slot, int next_slot, const float *prev_xy, int n,
+                float *next_xy, uint8_t *status, float *err, const ktlvo_lk_params *p);
+int ktlvo_pyrlk_dev(ktlvo_ctx *ctx, int prev_slot, int next_slot, const float *d_prev_xy, int n,
+                    float *d_next_xy, uint8_t *d_status, float *d_err, const ktlvo_lk_params *p);
+/* n_pairs independent calls in one launch; point arrays are [n_pairs][n_per_pair]. */
+int ktlvo_pyrlk_batch_dev(ktlvo_ctx *ctx, const int *prev_slots, const int *next_slots,
+                          int n_pairs, const float *d_prev_xy, int n_per_pair, float *d_next_xy,
+                          uint8_t *d_status, float *d_err, const ktlvo_lk_params *p);
+
+/* ---- corner detection --------------------------------------------------------------------- */
+/* gftt->detect(image(roi), keypoints) for a list of ROIs of one slot's level-0 image
+ * (featureTracking.cpp:408-430).  Output for ROI r starts at xy[2*r*cap_per_roi] /
+ * response[r*cap_per_roi]; coordinates are ROI-relative like cv::KeyPoint::pt; counts[r] is
+ * the number of corners of ROI r.  cap_per_roi >= params->max_corners. */
+int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi,
+                      const ktlvo_gftt_params *params, float *xy, float *response, int *counts,
+                      int cap_per_roi);
+/* Test hook: cornerHarris / cornerMinEigenVal response of one ROI (rw*rh floats). */
+int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *roi, int use_harris,
+                          double harris_k, float *out);
+/* adaptiveNonMaximalSuppresion(keypoints, numToKeep), featureTracking.cpp:258-311; in place. */
+int ktlvo_anms(ktlvo_ctx *ctx, float *xy, float *response, int *n_inout, int num_to_keep);
+
+/* ---- gates ---------------------------------------------------------------------------------- */
+/* Keep predicate of getOpticalFlow, featureTracking.cpp:223-248.  keep_idx receives the kept
+ * input indices in input order (order-preserving compaction), n_keep their number. */
+int ktlvo_fb_gate(ktlvo_ctx *ctx, const float *f1, const float *f2, const float *f1_checked, int n,
+                  int y_threshold, int *keep_idx, int *n_keep);
+/* Circular stereo-temporal check, featureTracking.cpp:486-501. */
+int ktlvo_circular_gate(ktlvo_ctx *ctx, const float *prev_cur_right, const float *cur_left_right,
+                        int n, int *keep_idx, int *n_keep);
+/* getOpticalFlow, featureTracking.cpp:181-256: forward LK, backward LK and the gate in one
+ * call; outputs are the kept (f1, f2) pairs and their input indices, in input order. */
+int ktlvo_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float *features_1, int n,
+                           int y_threshold, float *f1_sel, float *f2_sel, int *keep_idx,
+                           int *n_keep);
+
+/* ---- RANSAC pose ---------------------------------------------------------------------------- */
+/* PnPRansacCallback::computeError + findInliers for H models at once (the inner loop of
+ * cv::solvePnPRansac, visualOdometry.cpp:206-208).  Rt holds H x (R row-major 9, t 3) doubles,
+ * K = fx,fy,cx,cy; counts[h] = #{ |x - proj(R X + t)|^2 <= thr_sq }.  If best_mask is not
+ * NULL it receives the n-byte inlier mask of hypothesis mask_hyp. */
+int ktlvo_ransac_score(ktlvo_ctx *ctx, const float *X3, const float *x2, int n, const double *Rt,
+                       int H, const double K[4], float thr_sq, int *counts, int mask_hyp,
+                       uint8_t *best_mask);
+/* cv::solvePnPRansac(P3d, p2d, K, 0, rvec, tvec, false, iters, reproj, conf, inliers, P3P)
+ * as called by estimatePoseRANSAC (visualOdometry.cpp:177-217): hypotheses are drawn with
+ * cv::RNG((uint64)-1), solved by P3P, scored in one batch on the GPU, and OpenCV's sequential
+ * acceptance rule is replayed over the counts.  Returns KTLVO_OK and *found = 1/0. */
+int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const float *x2, int n, int max_iters,
+                           float reproj_err, double confidence, double rvec[3], double tvec[3],
+                           uint8_t *inlier_mask, int *n_inliers, int *found);
+
+/* ---- frame level ---------------------------------------------------------------------------- */
+/* stereoImageCallback(left, right), featureTracking.cpp:339-666: returns in *n the number of
+ * (DepthPoint, ImagePoint) pairs written (what the reference publishes on /image_points_last
+ * and /image_points_cur); 0 for the first frame. cap = capacity of both arrays. */
+int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, const uint8_t *right,
+                             ktlvo_depth_point *last, ktlvo_image_point *cur, int cap, int *n,
+                             int *new_key_frame);
+/* pointCloudCallback(last, cur), visualOdometry.cpp:240-356: T_local is the reference's
+ * transform_msg.transform (row-major 4x4 f32, msg/transform_msg.msg), T_global its mTcw. */
+int ktlvo_estimate_pose(ktlvo_ctx *ctx, const ktlvo_depth_point *last, const ktlvo_image_point *cur,
+                        int n, float T_local[16], float T_global[16], int *n_inliers);
+
+/* ---- profiling ------------------------------------------------------------------------------ */
+/* With profiling on, every launch of the kernels listed in the enum above is bracketed by
+ * hipEvents on the context's stream; ktlvo_profile_get synchronises and returns the summed
+ * device time and launch count since the last ktlvo_profile_reset. */
+int ktlvo_profile_enable(ktlvo_ctx *ctx, int on);
+int ktlvo_profile_reset(ktlvo_ctx *ctx);
+int ktlvo_profile_get(ktlvo_ctx *ctx, int kernel_id, double *total_ms, long long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KTLVO_H */

@@ -1,0 +1,238 @@
+// Context life cycle, stream handling, profiling events and error strings of libktlvo_hip.so.
+#include "ctx.hpp"
+
+#include <cstring>
+
+namespace ktlvo {
+
+int set_hip_error(ktlvo_ctx *ctx, hipError_t e, const char *what, const char *file, int line) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    if (ctx) ctx->last_error = buf;
+    return KTLVO_ERR_HIP;
+}
+
+static hipEvent_t take_event(ktlvo_ctx *ctx) {
+    Profiler &p = ctx->prof;
+    if (!p.pool.empty()) {
+        hipEvent_t e = p.pool.back();
+        p.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(ktlvo_ctx *c, int k) : ctx(c), kid(k) {
+    if (!ctx->prof.on) return;
+    a = take_event(ctx);
+    b = take_event(ctx);
+    if (a && b) (void)hipEventRecord(a, ctx->stream);
+}
+ProfScope::~ProfScope() {
+    if (!a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof.pending[kid].push_back({a, b});
+}
+
+int ensure_misc(ktlvo_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->misc_bytes) return KTLVO_OK;
+    if (ctx->d_misc) {
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KTLVO_HIP(ctx, hipFree(ctx->d_misc));
+        ctx->d_misc = nullptr;
+        ctx->misc_bytes = 0;
+    }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    KTLVO_HIP(ctx, hipMalloc(&ctx->d_misc, bytes));
+    ctx->misc_bytes = bytes;
+    return KTLVO_OK;
+}
+
+int effective_max_level(const ktlvo_ctx *ctx, int a, int b, int requested) {
+    int m = requested;
+    if (ctx->built[a] < m) m = ctx->built[a];
+    if (ctx->built[b] < m) m = ctx->built[b];
+    return m;
+}
+
+} // namespace ktlvo
+
+using namespace ktlvo;
+
+extern "C" int ktlvo_default_config(ktlvo_config *c) {
+    if (!c) return KTLVO_ERR_INVALID;
+    memset(c, 0, sizeof(*c));
+    c->width = 1242; c->height = 375;
+    c->fx = 707.0912; c->fy = 707.0912; c->cx = 601.8873; c->cy = 183.1104;
+    c->bf = 386.1448;
+    c->num_slots = 4;
+    c->max_level = 4;
+    c->win = 21;
+    c->max_points = 20000;
+    c->max_batch_pairs = MAX_BATCH;
+    c->x_subregions = 20; c->y_subregions = 8; c->max_per_subregion = 100;
+    c->x_boundary = 30; c->y_boundary = 30;
+    c->max_track_dis = 100;
+    c->anms_keep = 1000;
+    c->keyframe_min_tracked = 300;
+    c->ransac_iters = 300;
+    c->ransac_reproj = 0.1f;
+    c->ransac_conf = (double)0.99f;
+    c->max_hypotheses = 1024;
+    return KTLVO_OK;
+}
+
+extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
+    if (!cfg || cfg->width <= 0 || cfg->height <= 0 || cfg->num_slots <= 0 || cfg->max_level < 0 ||
+        cfg->max_level >= MAX_LEVELS || cfg->win < 3 || cfg->win + 2 > PAD || cfg->max_points <= 0 ||
+        cfg->max_batch_pairs <= 0 || cfg->max_batch_pairs > MAX_BATCH)
+        return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+        fprintf(stderr, "ktlvo_create: no HIP device %d (found %d)\n", device_id, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+    ktlvo_ctx *ctx = new ktlvo_ctx;
+    ctx->cfg = *cfg;
+    ctx->device = device_id;
+
+    // level geometry: OpenCV's buildOpticalFlowPyramid rule
+    int w = cfg->width, h = cfg->height;
+    size_t off = 0;
+    ctx->n_levels = 0;
+    for (int l = 0; l <= cfg->max_level; l++) {
+        ctx->lw[l] = w; ctx->lh[l] = h;
+        ctx->lpitch[l] = (w + 2 * PAD + 63) & ~63;
+        ctx->loff[l] = off;
+        off += (size_t)ctx->lpitch[l] * (h + 2 * PAD);
+        off = (off + 255) & ~(size_t)255;
+        ctx->n_levels = l + 1;
+        int nw = (w + 1) / 2, nh = (h + 1) / 2;
+        if (nw <= cfg->win || nh <= cfg->win) break;
+        w = nw; h = nh;
+    }
+    ctx->slot_bytes = off + 256; // tail slack: aligned 16-byte loads may run past the last row
+
+    bool ok = true;
+    ok = ok && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+    ctx->stream = ctx->own_stream;
+    ok = ok && hipMalloc((void **)&ctx->d_slab, ctx->slot_bytes * cfg->num_slots) == hipSuccess;
+    ok = ok && hipMemset(ctx->d_slab, 0, ctx->slot_bytes * cfg->num_slots) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_slots, sizeof(SlotDesc) * cfg->num_slots) == hipSuccess;
+    if (ok) {
+        ctx->h_slots.resize(cfg->num_slots);
+        ctx->built.assign(cfg->num_slots, -1);
+        for (int s = 0; s < cfg->num_slots; s++) {
+            memset(&ctx->h_slots[s], 0, sizeof(SlotDesc));
+            for (int l = 0; l < ctx->n_levels; l++) {
+                LevelDesc &d = ctx->h_slots[s].lv[l];
+                d.w = ctx->lw[l]; d.h = ctx->lh[l]; d.pitch = ctx->lpitch[l];
+                d.origin = ctx->d_slab + ctx->slot_bytes * s + ctx->loff[l] + (size_t)PAD * d.pitch + PAD;
+            }
+        }
+        ok = hipMemcpy(ctx->d_slots, ctx->h_slots.data(), sizeof(SlotDesc) * cfg->num_slots,
+                       hipMemcpyHostToDevice) == hipSuccess;
+    }
+    const size_t np = (size_t)cfg->max_points;
+    for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&ctx->d_pts[i], np * 2 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_status, np) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_err, np * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_idx, (np + 1) * sizeof(int)) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "ktlvo_create: device allocation failed: %s\n", hipGetErrorString(hipGetLastError()));
+        ktlvo_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+namespace ktlvo { void tracker_free(ktlvo_ctx *ctx); }
+
+extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    tracker_free(ctx);
+    for (int k = 0; k < KTLVO_K_COUNT; k++)
+        for (auto &pr : ctx->prof.pending[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; i++) if (ctx->d_pts[i]) (void)hipFree(ctx->d_pts[i]);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->d_idx) (void)hipFree(ctx->d_idx);
+    if (ctx->d_misc) (void)hipFree(ctx->d_misc);
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->d_slab) (void)hipFree(ctx->d_slab);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int ktlvo_set_stream(ktlvo_ctx *ctx, void *hip_stream) {
+    if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return KTLVO_OK;
+}
+
+extern "C" int ktlvo_sync(ktlvo_ctx *ctx) {
+    if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KTLVO_OK;
+}
+
+extern "C" const char *ktlvo_strerror(int s) {
+    switch (s) {
+    case KTLVO_OK: return "ok";
+    case KTLVO_ERR_INVALID: return "invalid argument";
+    case KTLVO_ERR_UNSUPPORTED: return "parameter value not supported by the HIP path";
+    case KTLVO_ERR_HIP: return "HIP runtime error";
+    case KTLVO_ERR_CAPACITY: return "capacity of the context exceeded";
+    case KTLVO_ERR_STATE: return "call order error (image or pyramid missing)";
+    case KTLVO_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *ktlvo_last_error(const ktlvo_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int ktlvo_profile_enable(ktlvo_ctx *ctx, int on) {
+    if (!ctx) return KTLVO_ERR_INVALID;
+    ctx->prof.on = on != 0;
+    return KTLVO_OK;
+}
+
+static int profile_drain(ktlvo_ctx *ctx) {
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    Profiler &p = ctx->prof;
+    for (int k = 0; k < KTLVO_K_COUNT; k++) {
+        for (auto &pr : p.pending[k]) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                p.total_ms[k] += ms;
+                p.launches[k] += 1;
+            }
+            p.pool.push_back(pr.first);
+            p.pool.push_back(pr.second);
+        }
+        p.pending[k].clear();
+    }
+    return KTLVO_OK;
+}
+
+extern "C" int ktlvo_profile_reset(ktlvo_ctx *ctx) {
+    if (!ctx) return KTLVO_ERR_INVALID;
+    int rc = profile_drain(ctx);
+    for (int k = 0; k < KTLVO_K_COUNT; k++) { ctx->prof.total_ms[k] = 0; ctx->prof.launches[k] = 0; }
+    return rc;
+}
+
+extern "C" int ktlvo_profile_get(ktlvo_ctx *ctx, int kid, double *total_ms, long long *launches) {
+    if (!ctx || kid < 0 || kid >= KTLVO_K_COUNT) return KTLVO_ERR_INVALID;
+    int rc = profile_drain(ctx);
+    if (total_ms) *total_ms = ctx->prof.total_ms[kid];
+    if (launches) *launches = ctx->prof.launches[kid];
+    return rc;
+}

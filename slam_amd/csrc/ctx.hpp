@@ -1,0 +1,106 @@
+// Internal declarations shared by the translation units of libktlvo_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "ktlvo.h"
+
+namespace ktlvo {
+
+constexpr int MAX_LEVELS = 8;
+// Every pyramid level is stored with a PAD-pixel frame on all sides.  The frame holds the
+// reflect-101 continuation of the level (what cv::buildOpticalFlowPyramid's copyMakeBorder
+// produces for `win` pixels), so the LK kernel never needs border index arithmetic.
+constexpr int PAD = 32;
+constexpr int MAX_BATCH = 64; // slots / pairs passed by value to one launch
+
+struct LevelDesc {
+    uint8_t *origin; // address of pixel (0,0)
+    int w, h, pitch; // pitch in bytes; pixel (x,y) valid for x in [-PAD, w+PAD), y in [-PAD, h+PAD)
+};
+struct SlotDesc {
+    LevelDesc lv[MAX_LEVELS];
+};
+struct SlotList {
+    int n;
+    int s[MAX_BATCH];
+};
+struct PairList {
+    int prev[MAX_BATCH];
+    int next[MAX_BATCH];
+};
+
+struct Profiler {
+    bool on = false;
+    std::vector<hipEvent_t> pool;                 // recycled events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KTLVO_K_COUNT];
+    double total_ms[KTLVO_K_COUNT] = {0, 0, 0, 0};
+    long long launches[KTLVO_K_COUNT] = {0, 0, 0, 0};
+};
+
+struct TrackerState; // tracker.hip
+
+} // namespace ktlvo
+
+struct ktlvo_ctx {
+    ktlvo_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr; // stream in use (own_stream or the caller's)
+    std::string last_error;
+
+    // image slots
+    int n_levels = 0; // levels allocated per slot (cfg.max_level limited by OpenCV's size rule)
+    int lw[ktlvo::MAX_LEVELS], lh[ktlvo::MAX_LEVELS], lpitch[ktlvo::MAX_LEVELS];
+    size_t loff[ktlvo::MAX_LEVELS];
+    size_t slot_bytes = 0;
+    uint8_t *d_slab = nullptr;
+    ktlvo::SlotDesc *d_slots = nullptr;
+    std::vector<ktlvo::SlotDesc> h_slots;
+    std::vector<int> built; // highest level holding valid data per slot, -1 = no image
+
+    // device scratch for the host-pointer entry points
+    float *d_pts[4] = {nullptr, nullptr, nullptr, nullptr}; // max_points x 2 floats each
+    uint8_t *d_status = nullptr;
+    float *d_err = nullptr;
+    int *d_idx = nullptr;   // max_points + 1 ints
+    void *d_misc = nullptr; // corner / ransac work area
+    size_t misc_bytes = 0;
+
+    ktlvo::Profiler prof;
+    ktlvo::TrackerState *tracker = nullptr;
+};
+
+namespace ktlvo {
+
+int set_hip_error(ktlvo_ctx *ctx, hipError_t e, const char *what, const char *file, int line);
+
+#define KTLVO_HIP(ctx, call)                                                                      \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return ktlvo::set_hip_error((ctx), e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// RAII bracket: records start/stop events around a launch when profiling is on.
+struct ProfScope {
+    ktlvo_ctx *ctx;
+    int kid;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ktlvo_ctx *c, int k);
+    ~ProfScope();
+};
+
+int ensure_misc(ktlvo_ctx *ctx, size_t bytes);
+inline bool slot_ok(const ktlvo_ctx *ctx, int s) { return s >= 0 && s < ctx->cfg.num_slots; }
+int effective_max_level(const ktlvo_ctx *ctx, int a, int b, int requested);
+
+// internal launchers (device pointers, asynchronous)
+int launch_pyrlk(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, int n_per_pair,
+                 float *d_next, uint8_t *d_status, float *d_err, const ktlvo_lk_params *p);
+
+} // namespace ktlvo
