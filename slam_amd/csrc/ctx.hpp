@@ -103,4 +103,11 @@ int effective_max_level(const ktlvo_ctx *ctx, int a, int b, int requested);
 int launch_pyrlk(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, int n_per_pair,
                  float *d_next, uint8_t *d_status, float *d_err, const ktlvo_lk_params *p);
 
+// General form: pair i reads prev[prev_off[i] ..] and writes next/status/err[next_off[i] ..];
+// if d_n is given the point count is read from device memory (capped by n_per_pair), so a chain
+// of gated stages can be enqueued without a host round trip.
+int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, const int *prev_off,
+                    float *d_next, const int *next_off, uint8_t *d_status, float *d_err, int n_per_pair,
+                    const int *d_n, const ktlvo_lk_params *p);
+
 } // namespace ktlvo

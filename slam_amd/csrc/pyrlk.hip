@@ -28,7 +28,10 @@ struct LkArgs {
     int max_count;
     double eps_sq;
     double min_eig_thr;
+    const int *d_n; // optional: actual point count lives in device memory (<= n_per_pair)
     PairList pairs;
+    int prev_off[MAX_BATCH]; // first point of pair i in prev[]
+    int next_off[MAX_BATCH]; // first point of pair i in next[], status[], err[]
 };
 
 __device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
@@ -99,12 +102,14 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int f = blockIdx.x * 4 + wave;
-    if (f >= a.n_per_pair) return;
+    const int n = a.d_n ? min(*a.d_n, a.n_per_pair) : a.n_per_pair;
+    if (f >= n) return;
     const int pair = blockIdx.y;
     const SlotDesc &SP = a.slots[a.pairs.prev[pair]];
     const SlotDesc &SN = a.slots[a.pairs.next[pair]];
-    const size_t gi = (size_t)pair * a.n_per_pair + f;
-    const float ppx = a.prev[2 * gi], ppy = a.prev[2 * gi + 1];
+    const size_t gp = (size_t)a.prev_off[pair] + f;
+    const size_t gi = (size_t)a.next_off[pair] + f;
+    const float ppx = a.prev[2 * gp], ppy = a.prev[2 * gp + 1];
 
     const bool active = lane < 63;
     const int c = active ? lane / 21 : 0;
@@ -263,6 +268,14 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
 
 int launch_pyrlk(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, int n_per_pair,
                  float *d_next, uint8_t *d_status, float *d_err, const ktlvo_lk_params *p) {
+    int po[MAX_BATCH], no[MAX_BATCH];
+    for (int i = 0; i < n_pairs && i < MAX_BATCH; i++) po[i] = no[i] = i * n_per_pair;
+    return launch_pyrlk_ex(ctx, pairs, n_pairs, d_prev, po, d_next, no, d_status, d_err, n_per_pair, nullptr, p);
+}
+
+int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, const int *prev_off,
+                    float *d_next, const int *next_off, uint8_t *d_status, float *d_err, int n_per_pair,
+                    const int *d_n, const ktlvo_lk_params *p) {
     if (!p) return KTLVO_ERR_INVALID;
     if (p->win != WIN) return KTLVO_ERR_UNSUPPORTED;
     if (n_pairs <= 0 || n_pairs > MAX_BATCH || n_per_pair < 0) return KTLVO_ERR_INVALID;
@@ -286,7 +299,9 @@ int launch_pyrlk(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float
     double eps = p->epsilon < 0 ? 0 : p->epsilon > 10 ? 10 : p->epsilon;
     a.eps_sq = eps * eps;
     a.min_eig_thr = p->min_eig_thr;
+    a.d_n = d_n;
     a.pairs = pairs;
+    for (int i = 0; i < n_pairs; i++) { a.prev_off[i] = prev_off[i]; a.next_off[i] = next_off[i]; }
     dim3 grid((n_per_pair + 3) / 4, n_pairs);
     ProfScope ps(ctx, KTLVO_K_PYRLK);
     hipLaunchKernelGGL(pyrlk_track_w21, grid, dim3(256), 0, ctx->stream, a);

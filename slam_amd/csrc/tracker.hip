@@ -1,6 +1,256 @@
-// Frame-level host logic (placeholder until the tracker lands).
+// Frame-level host logic: the control flow of the reference's two callbacks over the device ops.
+//   stereoImageCallback   featureTracking.cpp:339-666
+//   pointCloudCallback    visualOdometry.cpp:240-356 (estimatePoseRANSAC :177-217)
+//
+// Differences from the reference that do not change results: each image's pyramid is built once
+// and the cur -> last hand-over is a slot swap (the reference rebuilds 16 pyramids per frame for 4
+// distinct images); the 8 LK calls of a frame are enqueued as 6 launches with the gating and
+// compaction between them done on the device, so the host synchronises once per frame.
 #include "ctx.hpp"
+#include "internal.hpp"
+
+#include <cstring>
+
 namespace ktlvo {
-struct TrackerState {};
-void tracker_free(ktlvo_ctx *ctx) { delete ctx->tracker; ctx->tracker = nullptr; }
+
+struct TrackerState {
+    bool inited = false;
+    int sCurL = 0, sCurR = 1, sLastL = 2, sLastR = 3; // slot roles, swapped every frame
+    std::vector<ktlvo_image_point> imagePointsCur;     // featureTracking.cpp:122
+    float mTcw[16], mTcwLocal[16];                      // visualOdometry.cpp:113-114
+    // device work lists (max_points points each)
+    float *d_buf = nullptr;
+    int *d_int = nullptr;
+    enum { A = 0, BC = 1 /* two lists */, DE = 3 /* two lists */, S1 = 5, F2, CHK, T1, T2, G2, U1, U2, U3, NLIST };
+    float *list(int i, int cap) const { return d_buf + (size_t)i * cap * 2; }
+};
+
+void tracker_free(ktlvo_ctx *ctx) {
+    if (!ctx->tracker) return;
+    if (ctx->tracker->d_buf) (void)hipFree(ctx->tracker->d_buf);
+    if (ctx->tracker->d_int) (void)hipFree(ctx->tracker->d_int);
+    delete ctx->tracker;
+    ctx->tracker = nullptr;
+}
+
+static int tracker_get(ktlvo_ctx *ctx, TrackerState **out) {
+    if (!ctx->tracker) {
+        if (ctx->cfg.num_slots < 4) return KTLVO_ERR_CAPACITY;
+        TrackerState *t = new TrackerState;
+        for (int i = 0; i < 16; i++) t->mTcw[i] = t->mTcwLocal[i] = (i % 5 == 0) ? 1.f : 0.f;
+        const size_t cap = ctx->cfg.max_points;
+        if (hipMalloc((void **)&t->d_buf, (size_t)TrackerState::NLIST * cap * 8) != hipSuccess ||
+            hipMalloc((void **)&t->d_int, (3 * cap + 8) * sizeof(int)) != hipSuccess) {
+            if (t->d_buf) (void)hipFree(t->d_buf);
+            delete t;
+            return KTLVO_ERR_NOMEM;
+        }
+        ctx->tracker = t;
+    }
+    *out = ctx->tracker;
+    return KTLVO_OK;
+}
+
 } // namespace ktlvo
+
+using namespace ktlvo;
+
+extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, const uint8_t *right,
+                                        ktlvo_depth_point *last, ktlvo_image_point *cur, int cap, int *n_out,
+                                        int *new_key_frame) {
+    if (!ctx || !left || !right || !n_out || cap < 0 || (cap > 0 && (!last || !cur))) return KTLVO_ERR_INVALID;
+    *n_out = 0;
+    if (new_key_frame) *new_key_frame = 0;
+    TrackerState *t;
+    int rc = tracker_get(ctx, &t);
+    if (rc != KTLVO_OK) return rc;
+    const ktlvo_config &c = ctx->cfg;
+    const int W = c.width, H = c.height;
+
+    if (!t->inited) { // :349-356
+        if ((rc = ktlvo_upload_image(ctx, t->sCurL, left, W, H, W)) != KTLVO_OK) return rc;
+        if ((rc = ktlvo_upload_image(ctx, t->sCurR, right, W, H, W)) != KTLVO_OK) return rc;
+        const int s[2] = {t->sCurL, t->sCurR};
+        if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
+        t->inited = true;
+        return KTLVO_OK;
+    }
+    std::swap(t->sLastL, t->sCurL); // :361-365: last <- cur, then the new frame becomes cur
+    std::swap(t->sLastR, t->sCurR);
+    if ((rc = ktlvo_upload_image(ctx, t->sCurL, left, W, H, W)) != KTLVO_OK) return rc;
+    if ((rc = ktlvo_upload_image(ctx, t->sCurR, right, W, H, W)) != KTLVO_OK) return rc;
+    {
+        const int s[2] = {t->sCurL, t->sCurR};
+        if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
+    }
+
+    std::vector<float> featuresLastLeft; // :385-389
+    std::vector<int> featuresLastLeftIndeces;
+    featuresLastLeft.reserve(t->imagePointsCur.size() * 2);
+    for (const ktlvo_image_point &p : t->imagePointsCur) {
+        featuresLastLeft.push_back(p.u);
+        featuresLastLeft.push_back(p.v);
+        featuresLastLeftIndeces.push_back(p.ind);
+    }
+    t->imagePointsCur.clear();
+
+    bool newKeyFrame = false;
+    if ((int)featuresLastLeftIndeces.size() < c.keyframe_min_tracked) { // :406-441
+        const double subW = (double)(W - 2 * c.x_boundary) / (double)c.x_subregions;
+        const double subH = (double)(H - 2 * c.y_boundary) / (double)c.y_subregions;
+        const int n_roi = c.x_subregions * c.y_subregions;
+        std::vector<ktlvo_roi> rois(n_roi);
+        for (int i = 0; i < c.y_subregions; i++)
+            for (int j = 0; j < c.x_subregions; j++)
+                rois[i * c.x_subregions + j] = {c.x_boundary + (int)(subW * j), c.y_boundary + (int)(subH * i), (int)subW,
+                                                (int)subH};
+        const int capr = c.max_per_subregion;
+        std::vector<float> xy((size_t)n_roi * capr * 2), resp((size_t)n_roi * capr);
+        std::vector<int> counts(n_roi);
+        const ktlvo_gftt_params gp = {capr, 0.01, 10, 3, 1, 0.0}; // GFTTDetector::create(100,0.01,10,3,true,0.0), :103
+        rc = ktlvo_detect_gftt(ctx, t->sLastL, rois.data(), n_roi, &gp, xy.data(), resp.data(), counts.data(), capr);
+        if (rc != KTLVO_OK) return rc;
+        std::vector<float> kxy, kresp;
+        for (int r = 0; r < n_roi; r++)
+            for (int k = 0; k < counts[r]; k++) { // :423-428
+                kxy.push_back(xy[((size_t)r * capr + k) * 2] + rois[r].x);
+                kxy.push_back(xy[((size_t)r * capr + k) * 2 + 1] + rois[r].y);
+                kresp.push_back(0.f); // OpenCV 3 GFTTDetector: KeyPoint(pt, blockSize), response stays 0
+            }
+        int nk = (int)kresp.size();
+        if (nk > c.max_points) return KTLVO_ERR_CAPACITY;
+        rc = ktlvo_anms(ctx, kxy.data(), kresp.data(), &nk, c.anms_keep); // :433
+        if (rc != KTLVO_OK) return rc;
+        featuresLastLeft.assign(kxy.begin(), kxy.begin() + 2 * (size_t)nk); // :434
+        newKeyFrame = true;
+    }
+    if (new_key_frame) *new_key_frame = newKeyFrame ? 1 : 0;
+
+    const int N = (int)(featuresLastLeft.size() / 2);
+    if (N == 0) return KTLVO_OK;
+    if (N > c.max_points) return KTLVO_ERR_CAPACITY;
+    const int CAP = c.max_points;
+    typedef TrackerState TS;
+    float *dA = t->list(TS::A, CAP), *dBC = t->list(TS::BC, CAP), *dDE = t->list(TS::DE, CAP);
+    float *dS1 = t->list(TS::S1, CAP), *dF2 = t->list(TS::F2, CAP), *dCHK = t->list(TS::CHK, CAP);
+    float *dT1 = t->list(TS::T1, CAP), *dT2 = t->list(TS::T2, CAP), *dG2 = t->list(TS::G2, CAP);
+    float *dU1 = t->list(TS::U1, CAP), *dU2 = t->list(TS::U2, CAP), *dU3 = t->list(TS::U3, CAP);
+    int *dK1 = t->d_int, *dK2 = t->d_int + CAP, *dK3 = t->d_int + 2 * CAP, *dCnt = t->d_int + 3 * CAP;
+    const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4}; // :195-197, :208-209
+    const int sLL = t->sLastL, sLR = t->sLastR, sCL = t->sCurL, sCR = t->sCurR;
+
+    KTLVO_HIP(ctx, hipMemcpyAsync(dA, featuresLastLeft.data(), (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+    { // circular check :457-479: LL->LR and LL->CL share their input list
+        PairList pl;
+        pl.prev[0] = sLL; pl.next[0] = sLR;
+        pl.prev[1] = sLL; pl.next[1] = sCL;
+        const int po[2] = {0, 0}, no[2] = {0, N};
+        rc = launch_pyrlk_ex(ctx, pl, 2, dA, po, dBC, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
+        if (rc != KTLVO_OK) return rc;
+        // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft
+        pl.prev[0] = sLR; pl.next[0] = sCR;
+        pl.prev[1] = sCL; pl.next[1] = sCR;
+        const int po2[2] = {0, N};
+        rc = launch_pyrlk_ex(ctx, pl, 2, dBC, po2, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
+        if (rc != KTLVO_OK) return rc;
+    }
+    { // :486-501
+        Gather g;
+        g.src[0] = dA; g.dst[0] = dS1;
+        rc = launch_circular_gate(ctx, dDE, dDE + 2 * (size_t)N, N, dK1, dCnt + 0, g);
+        if (rc != KTLVO_OK) return rc;
+    }
+    { // getOpticalFlow(LastLeft, LastRight, selected, ..., y_threshold 1), :509
+        Gather g;
+        g.src[0] = dS1; g.dst[0] = dT1; // featuresLastLeftTemp
+        g.src[1] = dF2; g.dst[1] = dT2; // featuresLastRightTemp
+        rc = device_get_optical_flow(ctx, sLL, sLR, dS1, N, dCnt + 0, 1, dF2, dCHK, dK2, dCnt + 1, g);
+        if (rc != KTLVO_OK) return rc;
+    }
+    { // getOpticalFlow(LastLeft, CurLeft, ..., y_threshold 5, temporal), :513
+        Gather g;
+        g.src[0] = dT1; g.dst[0] = dU1; // featuresLastLeftSelect
+        g.src[1] = dG2; g.dst[1] = dU2; // featuresCurLeftSelect
+        g.src[2] = dT2; g.dst[2] = dU3; // featuresLastRightSelect (features_depth)
+        rc = device_get_optical_flow(ctx, sLL, sCL, dT1, N, dCnt + 1, 5, dG2, dCHK, dK3, dCnt + 2, g);
+        if (rc != KTLVO_OK) return rc;
+    }
+    int cnt[3];
+    KTLVO_HIP(ctx, hipMemcpyAsync(cnt, dCnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int n1 = cnt[0], n2 = cnt[1], n3 = cnt[2];
+    if (n3 == 0) return KTLVO_OK;
+    std::vector<float> U1((size_t)n3 * 2), U2((size_t)n3 * 2), U3((size_t)n3 * 2);
+    std::vector<int> K1(n1), K2(n2), K3(n3);
+    KTLVO_HIP(ctx, hipMemcpyAsync(U1.data(), dU1, (size_t)n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(U2.data(), dU2, (size_t)n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(U3.data(), dU3, (size_t)n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(K1.data(), dK1, (size_t)n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(K2.data(), dK2, (size_t)n2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(K3.data(), dK3, (size_t)n3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    // :526-573 disparity -> depth and output assembly
+    int nout = 0;
+    for (int i = 0; i < n3; i++) {
+        const float disparity = U1[2 * i] - U3[2 * i];
+        const float depth = (float)(c.bf / disparity);
+        const float mThDepth = (float)(c.bf * 70.0f / c.fx);
+        if (!(depth > 0 && depth < mThDepth)) continue;
+        int ind = i;
+        if (!newKeyFrame) ind = featuresLastLeftIndeces[K1[K2[K3[i]]]]; // curLeftIndeces[i]
+        ktlvo_image_point ip = {U2[2 * i], U2[2 * i + 1], ind};
+        t->imagePointsCur.push_back(ip);
+        if (nout < cap) {
+            ktlvo_depth_point dp = {U1[2 * i], U1[2 * i + 1], depth, 0, ind, newKeyFrame ? 1 : 0};
+            last[nout] = dp;
+            cur[nout] = ip;
+        }
+        ++nout;
+    }
+    *n_out = nout < cap ? nout : cap;
+    return nout <= cap ? KTLVO_OK : KTLVO_ERR_CAPACITY;
+}
+
+extern "C" int ktlvo_estimate_pose(ktlvo_ctx *ctx, const ktlvo_depth_point *last, const ktlvo_image_point *cur, int n,
+                                   float T_local[16], float T_global[16], int *n_inliers) {
+    if (!ctx || n < 0 || !T_local || !T_global || (n > 0 && (!last || !cur))) return KTLVO_ERR_INVALID;
+    TrackerState *t;
+    int rc = tracker_get(ctx, &t);
+    if (rc != KTLVO_OK) return rc;
+    const ktlvo_config &c = ctx->cfg;
+    std::vector<float> X3((size_t)3 * n), x2((size_t)2 * n);
+    for (int i = 0; i < n; i++) { // UnprojectStereo with mRwc = I, mOw = 0 (:153-167, :266-281)
+        const float z = last[i].depth, u = last[i].u, v = last[i].v;
+        X3[3 * i] = (float)((u - c.cx) * z / c.fx);
+        X3[3 * i + 1] = (float)((v - c.cy) * z / c.fy);
+        X3[3 * i + 2] = z;
+        x2[2 * i] = cur[i].u;
+        x2[2 * i + 1] = cur[i].v;
+    }
+    double rvec[3], tvec[3];
+    int ninl = 0, found = 0;
+    rc = ktlvo_solve_pnp_ransac(ctx, X3.data(), x2.data(), n, c.ransac_iters, c.ransac_reproj, c.ransac_conf, rvec, tvec,
+                                nullptr, &ninl, &found);
+    if (rc != KTLVO_OK) return rc;
+    if (found) { // Rodrigues + set_T_matrix; Mat::copyTo converts 64F -> 32F (:210-214)
+        double R[9];
+        rodrigues_v2m(rvec, R);
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) t->mTcwLocal[4 * i + j] = (float)R[3 * i + j];
+            t->mTcwLocal[4 * i + 3] = (float)tvec[i];
+        }
+    } // otherwise mTcw_local keeps its previous value
+    float out[16];
+    for (int i = 0; i < 4; i++) // mTcw = mTcw * mTcw_local (:326); cv::gemm accumulates f32 products in double
+        for (int j = 0; j < 4; j++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += (double)t->mTcw[4 * i + k] * (double)t->mTcwLocal[4 * k + j];
+            out[4 * i + j] = (float)s;
+        }
+    memcpy(t->mTcw, out, sizeof(out));
+    memcpy(T_local, t->mTcwLocal, sizeof(out));
+    memcpy(T_global, t->mTcw, sizeof(out));
+    if (n_inliers) *n_inliers = found ? ninl : -1;
+    return KTLVO_OK;
+}

@@ -9,6 +9,15 @@ import os
 
 import numpy as np
 
+# PyTorch-ROCm ships its own libamdhip64.so.7.  A process must hold exactly one HIP runtime, and
+# the loader only shares it when torch's copy is mapped first (our library then binds to the
+# already-loaded soname).  Harnesses that also use torch tensors or torch.distributed therefore
+# need torch imported before this library is opened; doing it here makes the order automatic.
+try:
+    import torch  # noqa: F401
+except ImportError:  # a torch-free process simply uses the system ROCm runtime
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libktlvo_hip.so")
 

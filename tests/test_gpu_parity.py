@@ -1,0 +1,345 @@
+"""GPU parity tests: every call goes through the C ABI of libktlvo_hip.so and is compared with
+the CPU oracle on the same seeded inputs and with the committed golden vectors.
+
+Bars: bit-exact for integer/byte/index work (pyramid, Scharr, corner sets, gates, inlier
+counts); LK positions within 0.05 px with >= 99.5 % identical status flags (the tolerance the
+task statement gives for the float accumulations of LK)."""
+import os
+
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LK_TOL_PX = 0.05
+LK_STATUS_AGREE = 0.995
+
+
+def _lk_compare(go, gs, ge, oo, os_, oe):
+    assert (gs == os_).mean() >= LK_STATUS_AGREE
+    both = (gs == 1) & (os_ == 1)
+    if both.any():
+        d = np.abs(go - oo).max(1)[both]
+        assert d.max() <= LK_TOL_PX, d.max()
+        assert np.abs(ge - oe)[both].max() <= 0.05
+    return both
+
+
+# ---------------------------------------------------------------- pyramid / Scharr ------------
+@pytest.mark.parametrize("size", [(1242, 375), (1241, 376), (197, 123), (640, 481)])
+def test_pyramid_and_scharr_bit_exact(make_ctx, oracle, size):
+    w, h = size
+    img = synth.texture_image(w, h, seed=w + h, periods=(24.0, 9.0, 4.0), noise=True)
+    ctx = make_ctx(width=w, height=h)
+    ctx.upload_image(0, img)
+    ctx.build_pyramid(0)
+    p = oracle.Pyramid(img, 4, 21)
+    assert ctx.pyramid_levels(0) == p.max_level
+    for l in range(p.max_level + 1):
+        o = p.level(l)
+        assert np.array_equal(ctx.download_level(0, l), o), l
+        assert np.array_equal(ctx.download_scharr(0, l, o.shape[1], o.shape[0]), p.deriv(l)), l
+
+
+def test_pyramid_kat_and_golden(make_ctx):
+    img = np.zeros((64, 96), np.uint8)
+    img[20, 30] = 255
+    ctx = make_ctx(width=96, height=64)
+    ctx.upload_image(0, img)
+    ctx.build_pyramid(0)
+    assert ctx.pyramid_levels(0) == 1
+    l1 = ctx.download_level(0, 1)
+    assert l1[10, 15] == 36 and l1[10, 14] == 6 and l1[9, 14] == 1
+    g = np.load(os.path.join(GOLD, "pyramid_197x123.npz"))
+    ctx = make_ctx(width=197, height=123)
+    ctx.upload_image(0, g["img"])
+    ctx.build_pyramid(0)
+    for l in range(int(g["max_level"]) + 1):
+        assert np.array_equal(ctx.download_level(0, l), g["level%d" % l])
+        lv = g["level%d" % l]
+        assert np.array_equal(ctx.download_scharr(0, l, lv.shape[1], lv.shape[0]), g["scharr%d" % l])
+
+
+def test_pyramid_batched_build_equals_single(make_ctx):
+    ctx = make_ctx(width=320, height=240, num_slots=6)
+    imgs = [synth.texture_image(320, 240, seed=s) for s in range(6)]
+    for s, im in enumerate(imgs):
+        ctx.upload_image(s, im)
+    ctx.build_pyramids(list(range(6)))
+    ctx2 = make_ctx(width=320, height=240, num_slots=1)
+    for s, im in enumerate(imgs):
+        ctx2.upload_image(0, im)
+        ctx2.build_pyramid(0)
+        for l in range(ctx.pyramid_levels(s) + 1):
+            assert np.array_equal(ctx.download_level(s, l), ctx2.download_level(0, l))
+
+
+# ---------------------------------------------------------------- LK --------------------------
+@pytest.mark.parametrize("shift", [(0.3, -0.2), (3.3, -1.7), (-9.5, 6.25)])
+def test_lk_matches_oracle_and_truth(make_ctx, oracle, shift):
+    W, H = 1241, 376
+    a, b = synth.texture_pair(W, H, 5, shift[0], shift[1], noise=True)
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.build_pyramids([0, 1])
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(-5, W + 5, 3000), rng.uniform(-5, H + 5, 3000)], 1).astype(np.float32)
+    go, gs, ge = ctx.pyrlk(0, 1, pts)
+    oo, os_, oe = oracle.pyrlk(a, b, pts, nthreads=8)
+    both = _lk_compare(go, gs, ge, oo, os_, oe)
+    inner = both & (pts[:, 0] > 40) & (pts[:, 0] < W - 40) & (pts[:, 1] > 40) & (pts[:, 1] < H - 40)
+    e = np.abs(go - pts - np.array(shift, np.float32))[inner]
+    assert np.median(e) < 0.02 and np.percentile(e, 95) < 0.1
+
+
+def test_lk_golden_and_edge_cases(make_ctx, klib):
+    g = np.load(os.path.join(GOLD, "lk_320x240.npz"))
+    ctx = make_ctx(width=320, height=240)
+    ctx.upload_image(0, g["prev"])
+    ctx.upload_image(1, g["next"])
+    ctx.build_pyramids([0, 1])
+    go, gs, ge = ctx.pyrlk(0, 1, g["pts"])
+    _lk_compare(go, gs, ge, g["out"], g["status"], g["err"])
+    # empty list is legal
+    o, s, e = ctx.pyrlk(0, 1, np.zeros((0, 2), np.float32))
+    assert o.shape == (0, 2)
+    # far outside the frame: status 0, err 0, position = input
+    o, s, e = ctx.pyrlk(0, 1, np.array([[-500.0, -500.0], [5000.0, 100.0]], np.float32))
+    assert list(s) == [0, 0] and list(e) == [0, 0]
+    # unsupported window is refused, not silently changed
+    with pytest.raises(klib.KtlvoError) as ei:
+        ctx.pyrlk(0, 1, g["pts"], klib.lk_params(win=15))
+    assert ei.value.status == klib.ERR_UNSUPPORTED
+    # tracking a slot without an image is a state error
+    with pytest.raises(klib.KtlvoError) as ei:
+        ctx.pyrlk(0, 3, g["pts"])
+    assert ei.value.status == klib.ERR_STATE
+    with pytest.raises(klib.KtlvoError) as ei:
+        ctx.pyrlk(0, 1, np.zeros((ctx.cfg.max_points + 1, 2), np.float32))
+    assert ei.value.status == klib.ERR_CAPACITY
+
+
+def test_lk_max_level_3_and_iteration_limits(make_ctx, oracle, klib):
+    a, b = synth.texture_pair(640, 480, 8, 4.2, 2.1)
+    ctx = make_ctx(width=640, height=480)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.build_pyramids([0, 1])
+    rng = np.random.default_rng(2)
+    pts = np.stack([rng.uniform(0, 640, 1000), rng.uniform(0, 480, 1000)], 1).astype(np.float32)
+    for ml, mc, eps in [(3, 30, 0.01), (4, 5, 0.01), (0, 30, 0.03), (2, 1, 0.5)]:
+        go, gs, ge = ctx.pyrlk(0, 1, pts, klib.lk_params(max_level=ml, max_count=mc, epsilon=eps))
+        oo, os_, oe = oracle.pyrlk(a, b, pts, max_level=ml, max_count=mc, epsilon=eps, nthreads=4)
+        _lk_compare(go, gs, ge, oo, os_, oe)
+
+
+def test_lk_full_size_properties(make_ctx):
+    """Size-independent properties at the benchmark's size: zero motion maps every trackable point
+    onto itself, and forward-backward tracking returns to the start."""
+    W, H = 1241, 376
+    scene = synth.CorridorScene(W, H, seed=0x5EED0002)
+    a, b = scene.render(0), scene.render(1)
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.upload_image(2, a)
+    ctx.build_pyramids([0, 1, 2])
+    rng = np.random.default_rng(7)
+    pts = np.stack([rng.uniform(40, W - 40, 2000), rng.uniform(40, H - 40, 2000)], 1).astype(np.float32)
+    o, s, e = ctx.pyrlk(0, 2, pts)
+    assert (np.abs(o - pts)[s == 1] < 1e-3).all() and (e[s == 1] < 1e-2).all()   # (x - 10) + 10 moves x by ulps
+    f, sf, _ = ctx.pyrlk(0, 1, pts)
+    r, sr, _ = ctx.pyrlk(1, 0, f)
+    ok = (sf == 1) & (sr == 1)
+    assert ok.mean() > 0.8
+    assert np.median(np.abs(r - pts)[ok]) < 0.05
+
+
+def test_lk_batch_equals_single_calls(make_ctx, klib):
+    import torch
+    W, H = 640, 360
+    ctx = make_ctx(width=W, height=H, num_slots=6)
+    for s in range(6):
+        ctx.upload_image(s, synth.texture_image(W, H, 30, dx=0.7 * s, dy=-0.4 * s))
+    ctx.build_pyramids(list(range(6)))
+    rng = np.random.default_rng(3)
+    n = 777
+    pts = np.stack([rng.uniform(0, W, (5, n)), rng.uniform(0, H, (5, n))], 2).astype(np.float32)
+    dp = torch.from_numpy(pts).cuda()
+    dn = torch.zeros_like(dp)
+    ds = torch.zeros((5, n), dtype=torch.uint8, device="cuda")
+    de = torch.zeros((5, n), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pyrlk_batch_dev([0, 1, 2, 3, 4], [1, 2, 3, 4, 5], dp.data_ptr(), n, dn.data_ptr(), ds.data_ptr(),
+                        de.data_ptr(), klib.lk_params())
+    ctx.sync()
+    for i in range(5):
+        o, s, e = ctx.pyrlk(i, i + 1, pts[i])
+        assert np.array_equal(o, dn[i].cpu().numpy()) and np.array_equal(s, ds[i].cpu().numpy())
+        assert np.array_equal(e, de[i].cpu().numpy())
+
+
+# ---------------------------------------------------------------- corners ---------------------
+def _same_corner_set(gxy, gresp, oxy, oresp):
+    assert gxy.shape == oxy.shape
+    assert np.array_equal(gxy, oxy)            # same corners in the same (response, address) order
+    assert np.array_equal(gresp, oresp)
+
+
+def test_corner_response_bit_exact(make_ctx, oracle):
+    img = synth.texture_image(260, 180, seed=31, periods=(20.0, 8.0, 3.0))
+    ctx = make_ctx(width=260, height=180)
+    ctx.upload_image(0, img)
+    for roi in [(30, 30, 59, 39), (0, 0, 260, 180), (201, 141, 59, 39), (5, 7, 33, 70)]:
+        for harris, k in [(True, 0.0), (True, 0.04), (False, 0.0)]:
+            g = ctx.corner_response(0, roi, harris, k)
+            o = oracle.corner_response(img, roi, harris, k)
+            assert np.array_equal(g, o), (roi, harris, k)
+
+
+def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
+    g = np.load(os.path.join(GOLD, "corners_260x180.npz"))
+    ctx = make_ctx(width=260, height=180)
+    ctx.upload_image(0, g["img"])
+    rois = [tuple(int(v) for v in r) for r in g["rois"]]
+    res = ctx.detect_gftt(0, rois, klib.gftt_params(100, 0.01, 10.0, 3, 1, 0.0))
+    for i, (xy, resp) in enumerate(res):
+        _same_corner_set(xy, resp, g["harris_xy%d" % i], g["harris_resp%d" % i])
+    res = ctx.detect_gftt(0, rois, klib.gftt_params(50, 0.01, 5.0, 3, 0, 0.0))
+    for i, (xy, resp) in enumerate(res):
+        _same_corner_set(xy, resp, g["mineig_xy%d" % i], g["mineig_resp%d" % i])
+    assert ctx.detect_gftt(0, [], klib.gftt_params()) == []
+    with pytest.raises(klib.KtlvoError):
+        ctx.detect_gftt(0, [(250, 170, 59, 39)], klib.gftt_params())   # ROI leaves the frame
+
+
+def test_gftt_reference_grid_and_full_frame(make_ctx, oracle, klib):
+    W, H = 1242, 375
+    scene = synth.CorridorScene(W, H, seed=3)
+    img = scene.render(0)
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, img)
+    subW, subH = (W - 60) / 20.0, (H - 60) / 8.0                      # featureTracking.cpp:76-77
+    rois = [(30 + int(subW * j), 30 + int(subH * i), int(subW), int(subH)) for i in range(8) for j in range(20)]
+    res = ctx.detect_gftt(0, rois, klib.gftt_params())
+    total = 0
+    for roi, (xy, resp) in zip(rois, res):
+        oxy, oresp = oracle.good_features(img, roi, 100, 0.01, 10.0, True, 0.0)
+        _same_corner_set(xy, resp, oxy, oresp)
+        total += len(xy)
+    assert total > 500
+    # whole frame, Shi-Tomasi, 2000 corners (the benchmark's detector setting): host-side selection path
+    (xy, resp), = ctx.detect_gftt(0, [(0, 0, W, H)], klib.gftt_params(2000, 0.01, 10.0, 3, 0, 0.0))
+    oxy, oresp = oracle.good_features(img, None, 2000, 0.01, 10.0, False, 0.0)
+    _same_corner_set(xy, resp, oxy, oresp)
+    assert len(xy) > 500
+
+
+def test_anms_matches_oracle(make_ctx, oracle):
+    ctx = make_ctx(width=320, height=240)
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(0, 500, (1500, 2)).astype(np.float32)
+    for resp in [np.zeros(1500, np.float32), rng.uniform(0.1, 1, 1500).astype(np.float32)]:
+        gxy, gresp = ctx.anms(xy, resp, 1000)
+        oxy, oresp, _ = oracle.anms(xy, resp, 1000)
+        assert np.array_equal(gxy, oxy) and np.array_equal(gresp, oresp)
+    gxy, _ = ctx.anms(xy[:900], np.zeros(900, np.float32), 1000)
+    assert np.array_equal(gxy, xy[:900])
+    gxy, _ = ctx.anms(xy[:1000], np.zeros(1000, np.float32), 1000)     # n == numToKeep: keep all
+    assert len(gxy) == 1000
+
+
+# ---------------------------------------------------------------- gates -----------------------
+def test_gates_match_oracle(make_ctx, oracle):
+    ctx = make_ctx()
+    rng = np.random.default_rng(5)
+    n = 5000
+    f1 = np.stack([rng.uniform(0, 1242, n), rng.uniform(0, 375, n)], 1).astype(np.float32)
+    f2 = (f1 + rng.normal(size=(n, 2)) * 40).astype(np.float32)
+    chk = (f1 + rng.normal(size=(n, 2)) * 4).astype(np.float32)
+    for yt in (1, 5):
+        keep = oracle.fb_gate(f1, f2, chk, 1242, 375, 30, 30, 100.0, yt)
+        idx = ctx.fb_gate(f1, f2, chk, yt)
+        assert np.array_equal(idx, np.nonzero(keep)[0])
+    pcr = (f1 + rng.normal(size=(n, 2)) * 2).astype(np.float32)
+    assert np.array_equal(ctx.circular_gate(pcr, f1), np.nonzero(oracle.circular_gate(pcr, f1))[0])
+    assert len(ctx.fb_gate(f1[:0], f2[:0], chk[:0], 1)) == 0
+    # none kept / all kept
+    assert len(ctx.circular_gate(f1 + 10, f1)) == 0
+    assert np.array_equal(ctx.circular_gate(f1, f1), np.arange(n))
+
+
+def test_get_optical_flow_matches_composition(make_ctx, oracle):
+    W, H = 1242, 375
+    a, b = synth.texture_pair(W, H, 9, 1.4, 0.3, noise=True)
+    ctx = make_ctx()
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.build_pyramids([0, 1])
+    rng = np.random.default_rng(1)
+    pts = np.stack([rng.uniform(0, W, 1500), rng.uniform(0, H, 1500)], 1).astype(np.float32)
+    s1, s2, idx = ctx.get_optical_flow(0, 1, pts, 1)
+    f2, _, _ = ctx.pyrlk(0, 1, pts)
+    chk, _, _ = ctx.pyrlk(1, 0, f2)
+    keep = np.nonzero(oracle.fb_gate(pts, f2, chk, W, H, 30, 30, 100.0, 1))[0]
+    assert np.array_equal(idx, keep) and np.array_equal(s1, pts[keep]) and np.array_equal(s2, f2[keep])
+    assert 100 < len(idx) < 1500
+
+
+# ---------------------------------------------------------------- RANSAC ----------------------
+def test_ransac_score_counts_exact(make_ctx, oracle):
+    g = np.load(os.path.join(GOLD, "ransac_400.npz"))
+    ctx = make_ctx()
+    rng = np.random.default_rng(9)
+    H = 64
+    Rt = np.zeros((H, 12))
+    for h in range(H):
+        Rt[h, :9] = oracle.rodrigues_v2m(g["rvec"] + rng.normal(size=3) * 1e-3).reshape(9)
+        Rt[h, 9:] = g["tvec"] + rng.normal(size=3) * 5e-3
+    for thr_sq in (np.float32(float(np.float32(0.1)) ** 2), np.float32(4.0)):
+        counts, mask = ctx.ransac_score(g["X3"], g["x2"], Rt, g["K"], thr_sq, mask_hyp=3)
+        for h in range(H):
+            c, m, _ = oracle.project_score(g["X3"], g["x2"], Rt[h], g["K"], thr_sq)
+            assert counts[h] == c, h
+            if h == 3:
+                assert np.array_equal(mask, m)
+    assert counts.max() > 50
+
+
+def test_ransac_score_large_batch(make_ctx, oracle):
+    """BASELINE config 3 shape: 1024 hypotheses x 8000 points."""
+    rng = np.random.default_rng(11)
+    K = np.array([1093.5, 1093.5, 960.0, 540.0])
+    n, H = 8000, 1024
+    R = oracle.rodrigues_v2m(np.array([0.003, -0.01, 0.001]))
+    t = np.array([0.02, -0.01, -0.8])
+    X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-3, 3, n), rng.uniform(4, 60, n)], 1).astype(np.float32)
+    Xc = X.astype(np.float64) @ R.T + t
+    uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
+    uv = (uv + rng.normal(size=uv.shape) * 0.5).astype(np.float32)
+    Rt = np.zeros((H, 12))
+    for h in range(H):
+        Rt[h, :9] = oracle.rodrigues_v2m(np.array([0.003, -0.01, 0.001]) + rng.normal(size=3) * 2e-4).reshape(9)
+        Rt[h, 9:] = t + rng.normal(size=3) * 2e-3
+    ctx = make_ctx(width=1920, height=1080, fx=K[0], fy=K[1], cx=K[2], cy=K[3])
+    counts = ctx.ransac_score(X, uv, Rt, K, np.float32(4.0))
+    for h in range(0, H, 37):
+        c, _, _ = oracle.project_score(X, uv, Rt[h], K, np.float32(4.0))
+        assert counts[h] == c
+    assert counts.max() > 4000
+
+
+def test_solve_pnp_ransac_matches_oracle(make_ctx, oracle):
+    g = np.load(os.path.join(GOLD, "ransac_400.npz"))
+    ctx = make_ctx()
+    r = ctx.solve_pnp_ransac(g["X3"], g["x2"])
+    assert r["ok"] and r["n_inliers"] == int(g["n_inliers"])
+    assert np.array_equal(r["mask"], g["mask"])
+    assert np.abs(r["rvec"] - g["rvec"]).max() < 1e-12 and np.abs(r["tvec"] - g["tvec"]).max() < 1e-12
+    r = ctx.solve_pnp_ransac(g["X3"][:3], g["x2"][:3])
+    assert not r["ok"]
+    r = ctx.solve_pnp_ransac(g["X3"][:0], g["x2"][:0])
+    assert not r["ok"]

@@ -1,0 +1,69 @@
+"""Frame-level parity on the GPU: ktlvo_track_stereo_frame / ktlvo_estimate_pose against the
+oracle's restatement of the reference's two callbacks on a synthetic stereo corridor."""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ate(traj, gt):
+    return float(np.sqrt(np.mean(np.sum((traj - gt) ** 2, axis=1))))
+
+
+def test_tracker_matches_oracle_on_corridor(make_ctx, oracle):
+    W, H, NF = 1242, 375, 12
+    scene = synth.CorridorScene(W, H, seed=0x5EED0001)
+    ctx = make_ctx()
+    ocfg = oracle.default_config(nthreads=8)
+    otr = oracle.Tracker(ocfg)
+    g_traj, o_traj, gt = [], [], []
+    Tgt = np.eye(4)
+    kf_seen = 0
+    for f in range(NF):
+        L, R = scene.stereo_pair(f)
+        gl, gc, gkf = ctx.track_stereo_frame(L, R)
+        ol, oc, okf = otr.track(L, R)
+        assert gkf == okf
+        kf_seen += int(gkf)
+        if f == 0:
+            assert len(gl) == 0 and len(ol) == 0
+            continue
+        # same features survive the gates, in the same order, with the same bookkeeping
+        assert len(gl) == len(ol) and len(gl) > 100, (f, len(gl), len(ol))
+        assert np.array_equal(gl["ind"], ol["ind"]) and np.array_equal(gc["ind"], oc["ind"])
+        assert np.array_equal(gl["newKeyFrame"], ol["newKeyFrame"])
+        # Positions are carried from frame to frame, so the per-call LK tolerance (0.05 px) applies
+        # to almost all points while a few chained ones may drift a little further.
+        d = np.concatenate([np.abs(gl["u"] - ol["u"]), np.abs(gl["v"] - ol["v"]), np.abs(gc["u"] - oc["u"]),
+                            np.abs(gc["v"] - oc["v"])])
+        worst, frac_ok = float(d.max()), float((d <= 0.05).mean())
+        assert frac_ok >= 0.995 and worst <= 0.25, (f, worst, frac_ok)
+        depth_dev = float(np.abs(gl["depth"] / ol["depth"] - 1).max())
+        assert depth_dev < 0.02, (f, depth_dev)
+        gn, gTl, gTg = ctx.estimate_pose(gl, gc)
+        on, oTl, oTg = otr.estimate_pose(ol, oc)
+        g_traj.append(gTg[:3, 3].copy())
+        o_traj.append(oTg[:3, 3].copy())
+        Tgt = Tgt @ scene.relative_pose(f - 1, f)
+        gt.append(Tgt[:3, 3].copy())
+    assert kf_seen >= 1
+    g_traj, o_traj, gt = np.array(g_traj), np.array(o_traj), np.array(gt)
+    ate_g, ate_o = _ate(g_traj, gt), _ate(o_traj, gt)
+    path = np.abs(gt[-1]).max()
+    assert path > 5.0
+    # both follow the ground truth, and they agree with each other within 1 % of the path length
+    assert ate_g < 0.1 * path and ate_o < 0.1 * path, (ate_g, ate_o)
+    assert _ate(g_traj, o_traj) <= 0.01 * path, _ate(g_traj, o_traj)
+
+
+def test_tracker_edge_cases(make_ctx, klib):
+    ctx = make_ctx()
+    flat = np.full((375, 1242), 128, np.uint8)
+    last, cur, kf = ctx.track_stereo_frame(flat, flat)
+    assert len(last) == 0 and not kf
+    last, cur, kf = ctx.track_stereo_frame(flat, flat)      # key frame on a featureless image: no corners, no crash
+    assert len(last) == 0 and kf
+    n, Tl, Tg = ctx.estimate_pose(last, cur)                # empty input: pose stays identity
+    assert n == -1 and np.array_equal(Tl, np.eye(4, dtype=np.float32)) and np.array_equal(Tg, Tl)
