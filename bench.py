@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Benchmark of the ktl_vo feature-tracking hot path on MI355X.
+
+Metric (BASELINE.json): tracked features/sec @1241x376, 21x21 pyramidal LK, maxLevel 4.
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident
+in HBM: P consecutive frame pairs of a synthetic KITTI-shaped sequence (BASELINE configs[1]:
+2000 Shi-Tomasi corners per frame, frame-pair stream), i.e. the Gaussian pyramids of the P+1
+frames (pyr_down_u8) and P calcOpticalFlowPyrLK-equivalents in one launch (pyrlk_track_w21).
+A tracked feature is a point that leaves that call with status 1.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Every rank runs the same amount of work on its own sequence (seed + rank): weak scaling, no
+data-path collective; per-rank statistics are gathered with one all_gather (RCCL) at the end.
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from slam_amd import lib as K  # noqa: E402  (raises if libktlvo_hip.so is missing: no fallback)
+from slam_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling
+WIN = 21
+
+
+def lk_bytes_per_feature(levels, win=WIN):
+    """Algorithmic bytes of one feature through `levels` pyramid levels: per level one template
+    fetch with a 1-px Scharr halo ((w+3)^2) and one search-window fetch ((w+1)^2), plus 29 B of
+    point I/O (8 in, 8+1+4 out, rounded up).  Independent of the iteration count."""
+    return levels * ((win + 3) ** 2 + (win + 1) ** 2) + 29
+
+
+def pyramid_bytes(w, h, max_level, win=WIN):
+    """Algorithmic bytes of one pyramid build: each level read once, the next written once."""
+    total, levels = 0, 1
+    for _ in range(max_level):
+        nw, nh = (w + 1) // 2, (h + 1) // 2
+        if nw <= win or nh <= win:
+            break
+        total += w * h + nw * nh
+        w, h = nw, nh
+        levels += 1
+    return total, levels
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per step (<= 63)")
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--width", type=int, default=1241)
+    ap.add_argument("--height", type=int, default=376)
+    ap.add_argument("--max-level", type=int, default=4)
+    ap.add_argument("--min-dist", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget (0 = skip)")
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
+    return ap.parse_args()
+
+
+def cpu_baseline(frames, pts, max_level, budget_s):
+    """The oracle (a port of the OpenCV path the reference calls) timed on the host cores: per
+    pair both pyramids, the previous image's Scharr planes and the LK loop, as one
+    cv::calcOpticalFlowPyrLK call does.  Bounded sample: the first pairs of the same workload,
+    repeated until the time budget is spent."""
+    import oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    n_pairs = min(len(frames) - 1, 4)
+    tracked, t0, reps = 0, time.perf_counter(), 0
+    while True:
+        for i in range(n_pairs):
+            pa = O.Pyramid(frames[i], max_level, WIN, True)
+            pb = O.Pyramid(frames[i + 1], max_level, WIN, False)
+            _, st, _ = O.pyrlk(pa, pb, pts[i], WIN, max_level, nthreads=cores)
+            tracked += int(st.sum())
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 1000:
+            break
+    return {"value": tracked / el, "unit": "tracked features/s", "cores": cores, "kind": "port",
+            "sample": "first %d frame pairs x %d features of the same workload, %d repetitions, %.1f s; "
+                      "pyramids + Scharr + LK per pair (one calcOpticalFlowPyrLK each), points range-split "
+                      "over %d threads" % (n_pairs, pts.shape[1], reps, el, cores)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, P, NF = a.width, a.height, a.pairs, a.features
+    assert 1 <= P <= 63
+    pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
+
+    # ---- synthetic input: one sequence per rank -----------------------------------------------
+    scene = synth.CorridorScene(W, H, seed=a.seed + rank)
+    frames = [scene.render(f) for f in range(P + 1)]
+    cfg = K.default_config(width=W, height=H, num_slots=P + 1, max_level=a.max_level, max_points=max(NF, 1024),
+                           cx=scene.cx, cy=scene.cy)
+    ctx = K.Context(cfg, device=local)
+    t_h2d = time.perf_counter()
+    for s, f in enumerate(frames):
+        ctx.upload_image(s, f)
+    t_h2d = time.perf_counter() - t_h2d
+    # corners of every pair's first frame, from the product detector (Shi-Tomasi, whole frame)
+    gp = K.gftt_params(NF, 0.01, a.min_dist, 3, 0, 0.0)
+    pts = np.zeros((P, NF, 2), np.float32)
+    for i in range(P):
+        (xy, _), = ctx.detect_gftt(i, [(0, 0, W, H)], gp)
+        if len(xy) < NF:
+            raise SystemExit("frame %d yields %d corners < %d; lower --min-dist" % (i, len(xy), NF))
+        pts[i] = xy
+    d_prev = torch.from_numpy(pts).to(dev)
+    d_next = torch.zeros_like(d_prev)
+    d_status = torch.zeros((P, NF), dtype=torch.uint8, device=dev)
+    d_err = torch.zeros((P, NF), dtype=torch.float32, device=dev)
+    lk = K.lk_params(WIN, a.max_level)
+    slots = list(range(P + 1))
+    prev_slots, next_slots = slots[:-1], slots[1:]
+
+    def step():
+        ctx.build_pyramids(slots)
+        ctx.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, d_next.data_ptr(), d_status.data_ptr(),
+                            d_err.data_ptr(), lk)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k3_ms, k3_n = ctx.profile_get(K.K_PYRLK)
+    k1_ms, k1_n = ctx.profile_get(K.K_PYRDOWN)
+    ctx.profile_enable(False)
+
+    tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rec = torch.tensor([float(P * NF), float(tracked), float(P), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(rec) for _ in range(world)]
+        dist.all_gather(gathered, rec)             # the only collective: fixed-size per-rank statistics
+        recs = torch.stack(gathered).cpu().numpy()
+    else:
+        recs = rec.cpu().numpy()[None]
+    t_max = float(el.item())
+
+    if rank == 0:
+        total_tracked = float(recs[:, 1].sum())
+        total_in = float(recs[:, 0].sum())
+        value = total_tracked * a.steps / t_max
+        bpf = lk_bytes_per_feature(levels)
+        k3_avg_s = (k3_ms / max(k3_n, 1)) * 1e-3
+        feats_per_launch = P * NF
+        achieved = bpf * feats_per_launch / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0
+        lv_bytes, w_, h_ = 0, W, H                  # bytes of one image's pyramid
+        for _ in range(levels):
+            lv_bytes += w_ * h_
+            w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
+        out = {
+            "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
+            "value": value,
+            "unit": "tracked features/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": t_max / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 -> i32 fixed point, f32 sums",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: %dx%d gray frame-pair stream, %d Shi-Tomasi corners/frame, "
+                            "maxLevel=%d (%d pyramid levels), 21x21 window, 30 it / eps 0.01" % (W, H, NF, a.max_level,
+                                                                                               levels),
+                "pairs_per_step": P,
+                "features_per_pair": NF,
+                "per_gpu_sequence": "corridor seed 0x%X + rank" % a.seed,
+                "features_in_per_step": total_in,
+                "tracked_per_step": total_tracked,
+                "pairs_per_s": float(recs[:, 2].sum()) * a.steps / t_max,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "pyrlk_track_w21",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
+                "traffic": None,
+                "bytes_model_per_feature": bpf,
+                # compulsory-unique traffic of one pair: both pyramids read once + point I/O
+                "bytes_floor_per_feature": (2 * lv_bytes + 29 * NF) / NF,
+                "avg_launch_ms": k3_avg_s * 1e3,
+                "launches": int(k3_n),
+                "features_per_launch": feats_per_launch,
+            },
+            "kernels": {
+                "pyr_down_u8": {"avg_ms_per_step": k1_ms / max(k1_n, 1), "images_per_step": P + 1,
+                                "algorithmic_bytes_per_image": pyr_bytes,
+                                "achieved_GBps": pyr_bytes * (P + 1) / max(k1_ms / max(k1_n, 1) * 1e-3, 1e-12) / 1e9},
+                "pyrlk_track_w21": {"avg_ms_per_step": k3_ms / max(k3_n, 1)},
+            },
+            "h2d_inclusive": {"value": total_tracked / world / (t_max / a.steps + t_h2d),
+                              "note": "rank-0 rate if the %d frames of a step were uploaded from pageable host "
+                                      "memory every step (%.1f ms); never the headline value" % (P + 1, t_h2d * 1e3)},
+            "per_rank": [{"features_in": r[0], "tracked": r[1], "k3_ms": r[3], "k1_ms": r[5], "elapsed_s": r[7]}
+                         for r in recs.tolist()],
+        }
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(frames, pts, a.max_level, a.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,7 +85,8 @@ typedef struct { float u, v; int ind; } ktlvo_image_point;                      
 typedef struct { float u, v, depth; int label, ind, newKeyFrame; } ktlvo_depth_point; /* pointDefinition.h:28-34 */
 
 /* Kernel identifiers for ktlvo_profile_get. */
-enum { KTLVO_K_PYRDOWN = 0, KTLVO_K_PYRLK = 1, KTLVO_K_CORNER = 2, KTLVO_K_RANSAC = 3, KTLVO_K_COUNT = 4 };
+enum { KTLVO_K_PYRDOWN = 0, KTLVO_K_PYRLK = 1, KTLVO_K_CORNER = 2, KTLVO_K_RANSAC = 3, KTLVO_K_SCHARR = 4,
+       KTLVO_K_COUNT = 5 };
 
 /* ---- life cycle ----------------------------------------------------------------------- */
 /* Fills the reference's constants (cameraParameters.h:16-27, featureTracking.cpp:68-81,
@@ -107,7 +108,9 @@ int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int 
 int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride);
 /* cv::buildOpticalFlowPyramid as called inside calcOpticalFlowPyrLK (featureTracking.cpp:205):
  * pyrDown per level, reflect-101 border of `win` pixels.  Level count follows OpenCV's rule
- * (stop when the next level is not larger than the window). */
+ * (stop when the next level is not larger than the window).  The per-level Scharr planes that
+ * calcOpticalFlowPyrLK derives for its first image (calcSharrDeriv, zero border) are built in
+ * the same call, so any slot can serve as `prev`. */
 int ktlvo_build_pyramid(ktlvo_ctx *ctx, int slot, int max_level, int win);
 /* The same for several slots in one set of launches. */
 int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slots, int max_level, int win);

@@ -109,6 +109,9 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
         ctx->loff[l] = off;
         off += (size_t)ctx->lpitch[l] * (h + 2 * PAD);
         off = (off + 255) & ~(size_t)255;
+        ctx->doff[l] = off;
+        off += (size_t)ctx->lpitch[l] * (h + 2 * PAD) * 4;
+        off = (off + 255) & ~(size_t)255;
         ctx->n_levels = l + 1;
         int nw = (w + 1) / 2, nh = (h + 1) / 2;
         if (nw <= cfg->win || nh <= cfg->win) break;
@@ -125,12 +128,15 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
     if (ok) {
         ctx->h_slots.resize(cfg->num_slots);
         ctx->built.assign(cfg->num_slots, -1);
+        ctx->deriv_ok.assign(cfg->num_slots, 0);
         for (int s = 0; s < cfg->num_slots; s++) {
             memset(&ctx->h_slots[s], 0, sizeof(SlotDesc));
             for (int l = 0; l < ctx->n_levels; l++) {
                 LevelDesc &d = ctx->h_slots[s].lv[l];
                 d.w = ctx->lw[l]; d.h = ctx->lh[l]; d.pitch = ctx->lpitch[l];
-                d.origin = ctx->d_slab + ctx->slot_bytes * s + ctx->loff[l] + (size_t)PAD * d.pitch + PAD;
+                uint8_t *slot = ctx->d_slab + ctx->slot_bytes * s;
+                d.origin = slot + ctx->loff[l] + (size_t)PAD * d.pitch + PAD;
+                d.dorigin = reinterpret_cast<uint32_t *>(slot + ctx->doff[l]) + (size_t)PAD * d.pitch + PAD;
             }
         }
         ok = hipMemcpy(ctx->d_slots, ctx->h_slots.data(), sizeof(SlotDesc) * cfg->num_slots,

@@ -20,8 +20,9 @@ constexpr int PAD = 32;
 constexpr int MAX_BATCH = 64; // slots / pairs passed by value to one launch
 
 struct LevelDesc {
-    uint8_t *origin; // address of pixel (0,0)
-    int w, h, pitch; // pitch in bytes; pixel (x,y) valid for x in [-PAD, w+PAD), y in [-PAD, h+PAD)
+    uint8_t *origin;   // address of pixel (0,0)
+    uint32_t *dorigin; // Scharr plane, element (0,0): int16 dx | int16 dy << 16; zero outside the level
+    int w, h, pitch;   // pitch in elements (both planes); (x,y) addressable for x in [-PAD, w+PAD), y likewise
 };
 struct SlotDesc {
     LevelDesc lv[MAX_LEVELS];
@@ -39,8 +40,8 @@ struct Profiler {
     bool on = false;
     std::vector<hipEvent_t> pool;                 // recycled events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KTLVO_K_COUNT];
-    double total_ms[KTLVO_K_COUNT] = {0, 0, 0, 0};
-    long long launches[KTLVO_K_COUNT] = {0, 0, 0, 0};
+    double total_ms[KTLVO_K_COUNT] = {0, 0, 0, 0, 0};
+    long long launches[KTLVO_K_COUNT] = {0, 0, 0, 0, 0};
 };
 
 struct TrackerState; // tracker.hip
@@ -57,12 +58,14 @@ struct ktlvo_ctx {
     // image slots
     int n_levels = 0; // levels allocated per slot (cfg.max_level limited by OpenCV's size rule)
     int lw[ktlvo::MAX_LEVELS], lh[ktlvo::MAX_LEVELS], lpitch[ktlvo::MAX_LEVELS];
-    size_t loff[ktlvo::MAX_LEVELS];
+    size_t loff[ktlvo::MAX_LEVELS];  // image plane offset inside a slot
+    size_t doff[ktlvo::MAX_LEVELS];  // Scharr plane offset inside a slot
     size_t slot_bytes = 0;
     uint8_t *d_slab = nullptr;
     ktlvo::SlotDesc *d_slots = nullptr;
     std::vector<ktlvo::SlotDesc> h_slots;
-    std::vector<int> built; // highest level holding valid data per slot, -1 = no image
+    std::vector<int> built;    // highest level holding valid data per slot, -1 = no image
+    std::vector<int> deriv_ok; // Scharr planes of the built levels are valid
 
     // device scratch for the host-pointer entry points
     float *d_pts[4] = {nullptr, nullptr, nullptr, nullptr}; // max_points x 2 floats each

@@ -105,20 +105,42 @@ __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotLi
     }
 }
 
-// Scharr derivative of one level (calcSharrDeriv), used by the test hook only; the LK kernel
-// computes the same expression on the fly from the padded image.
-__global__ __launch_bounds__(256) void scharr_level(const SlotDesc *slots, int slot, int level, short2 *out) {
-    const LevelDesc L = slots[slot].lv[level];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= L.w || y >= L.h) return;
-    const uint8_t *p = L.origin + (ptrdiff_t)y * L.pitch + x;
-    const int P = L.pitch;
-    const int a00 = p[-P - 1], a01 = p[-P], a02 = p[-P + 1];
-    const int a10 = p[-1], a12 = p[1];
-    const int a20 = p[P - 1], a21 = p[P], a22 = p[P + 1];
-    const int dx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
-    const int dy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
-    out[(size_t)y * L.w + x] = make_short2((short)dx, (short)dy);
+// calcSharrDeriv for every level of the listed slots in one launch: grid (tiles of level 0, level,
+// slot).  A thread produces four consecutive pixels (one 16-byte store of four dx|dy pairs) from
+// three rows of the padded image, whose frame supplies calcSharrDeriv's reflect-101 neighbours.
+// Only the interior of the plane is written; its frame stays zero (copyMakeBorder BORDER_CONSTANT).
+__global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, SlotList list, int n_levels) {
+    const int level = blockIdx.y;
+    if (level >= n_levels) return;
+    const LevelDesc L = slots[list.s[blockIdx.z]].lv[level];
+    const int qw = (L.w + 3) >> 2;                 // quads per row
+    const int q = blockIdx.x * 256 + threadIdx.x;  // quad index in raster order
+    if (q >= qw * L.h) return;
+    const int y = q / qw, x0 = (q - y * qw) * 4;
+    // bytes x0-4 .. x0+7 of rows y-1, y, y+1 (origin and pitch are multiples of 4)
+    uint32_t d[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
+        d[j][0] = p[0]; d[j][1] = p[1]; d[j][2] = p[2];
+    }
+    auto B = [&](int j, int k) -> int { // pixel x0 + k, k in -1..4
+        const int b = k + 4;
+        return (int)((d[j][b >> 2] >> (8 * (b & 3))) & 0xffu);
+    };
+    uint32_t out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int dx = 3 * ((B(0, k + 1) - B(0, k - 1)) + (B(2, k + 1) - B(2, k - 1))) + 10 * (B(1, k + 1) - B(1, k - 1));
+        const int dy = 3 * ((B(2, k - 1) - B(0, k - 1)) + (B(2, k + 1) - B(0, k + 1))) + 10 * (B(2, k) - B(0, k));
+        out[k] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+    }
+    uint32_t *o = L.dorigin + (ptrdiff_t)y * L.pitch + x0;
+    if (x0 + 3 < L.w) {
+        *reinterpret_cast<uint4 *>(o) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+        for (int k = 0; k < 4 && x0 + k < L.w; k++) o[k] = out[k];
+    }
 }
 
 static int ingest(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride, hipMemcpyKind kind) {
@@ -133,6 +155,7 @@ static int ingest(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, in
     hipLaunchKernelGGL(pad_border_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, 0);
     KTLVO_HIP(ctx, hipGetLastError());
     ctx->built[slot] = 0;
+    ctx->deriv_ok[slot] = 0;
     return KTLVO_OK;
 }
 
@@ -170,8 +193,15 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
             hipLaunchKernelGGL(pyr_down_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, l);
         }
         KTLVO_HIP(ctx, hipGetLastError());
+        {
+            ProfScope ps2(ctx, KTLVO_K_SCHARR);
+            const int quads0 = ((ctx->lw[0] + 3) / 4) * ctx->lh[0];
+            dim3 grid((quads0 + 255) / 256, top + 1, list.n);
+            hipLaunchKernelGGL(scharr_planes, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, top + 1);
+            KTLVO_HIP(ctx, hipGetLastError());
+        }
     }
-    for (int i = 0; i < n_slots; i++) ctx->built[slots[i]] = top;
+    for (int i = 0; i < n_slots; i++) { ctx->built[slots[i]] = top; ctx->deriv_ok[slots[i]] = 1; }
     return KTLVO_OK;
 }
 
@@ -198,15 +228,10 @@ extern "C" int ktlvo_download_level(ktlvo_ctx *ctx, int slot, int level, uint8_t
 
 extern "C" int ktlvo_download_scharr(ktlvo_ctx *ctx, int slot, int level, int16_t *dst) {
     if (!ctx || !slot_ok(ctx, slot) || !dst || level < 0) return KTLVO_ERR_INVALID;
-    if (level > ctx->built[slot]) return KTLVO_ERR_STATE;
+    if (level > ctx->built[slot] || !ctx->deriv_ok[slot]) return KTLVO_ERR_STATE;
     const LevelDesc &L = ctx->h_slots[slot].lv[level];
-    const size_t bytes = (size_t)L.w * L.h * 4;
-    int rc = ensure_misc(ctx, bytes);
-    if (rc != KTLVO_OK) return rc;
-    dim3 grid((L.w + 63) / 64, (L.h + 3) / 4);
-    hipLaunchKernelGGL(scharr_level, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, level, (short2 *)ctx->d_misc);
-    KTLVO_HIP(ctx, hipGetLastError());
-    KTLVO_HIP(ctx, hipMemcpyAsync(dst, ctx->d_misc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)L.w * 4, L.dorigin, (size_t)L.pitch * 4, (size_t)L.w * 4, L.h,
+                                    hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KTLVO_OK;
 }

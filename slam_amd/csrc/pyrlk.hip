@@ -7,9 +7,12 @@
 // columns 7*(l / 21) ..+6), lane 63 idles.  A lane keeps its seven template values I, Ix, Iy in
 // registers for the whole level, so the template never touches LDS; per Gauss-Newton step a
 // lane fetches two 8-byte runs of the next image (rows r and r+1) and forms its seven bilinear
-// samples from them.  The 2x2 tensor and the mismatch vector are summed across the wave with
-// DPP row operations.  Scharr derivatives (calcSharrDeriv) are computed on the fly from a
-// 4x10 pixel neighbourhood of the padded previous image, so no derivative plane is stored.
+// samples from them with v_perm_b32 + v_dot2 (two taps per instruction).  The 2x2 tensor and the
+// mismatch vector are summed across the wave with DPP row operations.  Derivatives come from the
+// Scharr planes built with the pyramid (int16 dx|dy per pixel, zero outside the level).
+//
+// The kernel is VALU-bound (rocprof: VALU busy > 95 %), so the design minimises instructions per
+// pixel and per iteration rather than bytes: images and planes stay L2-resident.
 //
 // Arithmetic follows OpenCV's fixed-point scheme exactly (14-bit bilinear weights, CV_DESCALE,
 // int16 patch values, 2^-20 scale); only the accumulation order of the float sums differs.
@@ -34,65 +37,83 @@ struct LkArgs {
     int next_off[MAX_BATCH]; // first point of pair i in next[], status[], err[]
 };
 
-__device__ __forceinline__ float dpp_add(float v, const int ctrl, const int row_mask) {
-    // v + (v moved by the DPP pattern); lanes outside row_mask add 0
-    int moved;
-    switch (ctrl) { // the control word must be an immediate
-    case 0xB1: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false); break;
-    case 0x4E: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false); break;
-    case 0x141: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false); break;
-    case 0x140: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false); break;
-    case 0x142: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false); break;
-    default: moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false); break;
-    }
-    (void)row_mask;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) uint32_t *gptr32; // planes live in global memory
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    // v + (v moved by the DPP pattern); lanes outside ROW_MASK add 0
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
     return v + __int_as_float(moved);
 }
 
 // Sum over the 64 lanes, returned wave-uniform.  Fixed tree, so the result is deterministic.
 __device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add(v, 0xB1, 0xF);  // quad_perm [1,0,3,2]
-    v = dpp_add(v, 0x4E, 0xF);  // quad_perm [2,3,0,1]
-    v = dpp_add(v, 0x141, 0xF); // row_half_mirror
-    v = dpp_add(v, 0x140, 0xF); // row_mirror: every lane holds its 16-lane row sum
-    v = dpp_add(v, 0x142, 0xA); // row_bcast15 into rows 1 and 3
-    v = dpp_add(v, 0x143, 0xC); // row_bcast31 into rows 2 and 3
+    v = dpp_add<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v); // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v); // row_mirror: every lane holds its 16-lane row sum
+    v = dpp_add<0x142, 0xA>(v); // row_bcast15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v); // row_bcast31 into rows 2 and 3
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// N+1 aligned dwords starting at the dword holding p, shifted so that out[] begins at byte p.
-template <int N>
-__device__ __forceinline__ void load_bytes(const uint8_t *p, uint32_t (&out)[N]) {
-    // image planes live in global memory; say so, or the loads become flat_load
-    typedef const __attribute__((address_space(1))) uint32_t *gptr;
-    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
-    gptr q = (gptr)(p - sh);
-    uint32_t d[N + 1];
-#pragma unroll
-    for (int i = 0; i <= N; i++) d[i] = q[i];
-#pragma unroll
-    for (int i = 0; i < N; i++) out[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+// a * b + c on 24-bit signed factors (every factor here is below 2^15 in magnitude); written as
+// asm because clang has no builtin for it and falls back to the quarter-rate 32-bit multiply.
+__device__ __forceinline__ int mad24(int a, int b, int c) {
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
-template <int N>
-__device__ __forceinline__ int byte_at(const uint32_t (&d)[N], int k) {
-    return (int)((d[k >> 2] >> (8 * (k & 3))) & 0xffu);
-}
-
-__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
-// 24-bit multiply: every product below has factors under 2^15 in magnitude
-__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
-
+// Bilinear weights as OpenCV forms them: cvRound of float products scaled by 2^14, the fourth
+// as the remainder.  w01 = top pair (w00 | w01 << 16), w23 = bottom pair (w10 | w11 << 16).
 struct Weights {
-    int w00, w01, w10, w11;
+    uint32_t w01, w23;
 };
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
+    const int w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+    const int w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+    const int w10 = __float2int_rn((1.f - a) * b * 16384.f);
+    const int w11 = 16384 - w00 - w01 - w10;
     Weights w;
-    w.w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
-    w.w01 = __float2int_rn(a * (1.f - b) * 16384.f);
-    w.w10 = __float2int_rn((1.f - a) * b * 16384.f);
-    w.w11 = 16384 - w.w00 - w.w01 - w.w10;
+    w.w01 = (uint32_t)w00 | ((uint32_t)w01 << 16);
+    w.w23 = (uint32_t)w10 | ((uint32_t)w11 << 16); // w10 >= 0, so no sign bits leak into the high half
     return w;
+}
+
+// Eight consecutive bytes starting at an arbitrary byte address, as two dwords.
+struct Run8 {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ Run8 load_run8(const uint8_t *p) {
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+    gptr32 q = (gptr32)(p - sh);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+    Run8 r;
+    r.lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    r.hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return r;
+}
+// bytes i and i+1 of a run, zero-extended into a u16 pair
+template <int I>
+__device__ __forceinline__ uint32_t pix_pair(const Run8 &r) {
+    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)I | ((uint32_t)(I + 1) << 16);
+    return __builtin_amdgcn_perm(r.hi, r.lo, sel);
+}
+// the seven fixed-point bilinear samples (scaled by 32) of a lane's run
+__device__ __forceinline__ void sample_run(const Run8 &t, const Run8 &b, const Weights &w, int (&v)[7]) {
+    // signed dot: the remainder weight w11 can be -1 when the three rounded weights sum to 16385
+#define KTLVO_SAMPLE(I) v[I] = sdot2(pix_pair<I>(b), w.w23, sdot2(pix_pair<I>(t), w.w01, 256)) >> 9
+    KTLVO_SAMPLE(0); KTLVO_SAMPLE(1); KTLVO_SAMPLE(2); KTLVO_SAMPLE(3); KTLVO_SAMPLE(4); KTLVO_SAMPLE(5); KTLVO_SAMPLE(6);
+#undef KTLVO_SAMPLE
 }
 
 constexpr int WIN = 21;
@@ -138,41 +159,25 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         }
         Weights w = bilinear_weights(px - ipx, py - ipy);
 
-        // ---- template: rows ipy+r-1 .. ipy+r+2, columns ipx+cx-1 .. ipx+cx+8 ------------------
+        // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
         int Iv[RUN], ixv[RUN], iyv[RUN];
         {
-            uint32_t rowd[4][3];
-            const uint8_t *base = I.origin + (ptrdiff_t)(ipy + r - 1) * I.pitch + (ipx + cx - 1);
+            const ptrdiff_t e0 = (ptrdiff_t)(ipy + r) * I.pitch + (ipx + cx);
+            const Run8 t = load_run8(I.origin + e0), b = load_run8(I.origin + e0 + I.pitch);
+            gptr32 dt = (gptr32)(I.dorigin + e0), db = (gptr32)(I.dorigin + e0 + I.pitch);
+            uint32_t d0[RUN + 1], d1[RUN + 1];
 #pragma unroll
-            for (int j = 0; j < 4; j++) load_bytes<3>(base + (ptrdiff_t)j * I.pitch, rowd[j]);
-            // derivative buffers are zero outside the level (copyMakeBorder BORDER_CONSTANT)
-            const int gx0 = ipx + cx, gy0 = ipy + r;
-            const bool rowok[2] = {gy0 >= 0 && gy0 < I.h, gy0 + 1 >= 0 && gy0 + 1 < I.h};
-            int dxv[2][RUN + 1], dyv[2][RUN + 1];
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int k = 0; k <= RUN; k++) {
-                    // position (row j+1, byte k+1) of the 4x10 neighbourhood
-                    const int a00 = byte_at(rowd[j], k), a01 = byte_at(rowd[j], k + 1), a02 = byte_at(rowd[j], k + 2);
-                    const int a10 = byte_at(rowd[j + 1], k), a12 = byte_at(rowd[j + 1], k + 2);
-                    const int a20 = byte_at(rowd[j + 2], k), a21 = byte_at(rowd[j + 2], k + 1),
-                              a22 = byte_at(rowd[j + 2], k + 2);
-                    const bool ok = rowok[j] && (gx0 + k >= 0) && (gx0 + k < I.w);
-                    const int dx = m24(3, (a02 - a00) + (a22 - a20)) + m24(10, a12 - a10);
-                    const int dy = m24(3, (a20 - a00) + (a22 - a02)) + m24(10, a21 - a01);
-                    dxv[j][k] = ok ? dx : 0;
-                    dyv[j][k] = ok ? dy : 0;
-                }
+            for (int k = 0; k <= RUN; k++) { d0[k] = dt[k]; d1[k] = db[k]; }
+            sample_run(t, b, w, Iv);
 #pragma unroll
             for (int i = 0; i < RUN; i++) {
-                const int p00 = byte_at(rowd[1], i + 1), p01 = byte_at(rowd[1], i + 2);
-                const int p10 = byte_at(rowd[2], i + 1), p11 = byte_at(rowd[2], i + 2);
-                Iv[i] = descale(m24(p00, w.w00) + m24(p01, w.w01) + m24(p10, w.w10) + m24(p11, w.w11), 14 - 5);
-                const int ix = descale(m24(dxv[0][i], w.w00) + m24(dxv[0][i + 1], w.w01) + m24(dxv[1][i], w.w10) +
-                                       m24(dxv[1][i + 1], w.w11), 14);
-                const int iy = descale(m24(dyv[0][i], w.w00) + m24(dyv[0][i + 1], w.w01) + m24(dyv[1][i], w.w10) +
-                                       m24(dyv[1][i + 1], w.w11), 14);
+                // (dx_i, dx_i+1) and (dy_i, dy_i+1) as int16 pairs
+                const uint32_t xt = __builtin_amdgcn_perm(d0[i + 1], d0[i], 0x05040100u);
+                const uint32_t yt = __builtin_amdgcn_perm(d0[i + 1], d0[i], 0x07060302u);
+                const uint32_t xb = __builtin_amdgcn_perm(d1[i + 1], d1[i], 0x05040100u);
+                const uint32_t yb = __builtin_amdgcn_perm(d1[i + 1], d1[i], 0x07060302u);
+                const int ix = sdot2(xb, w.w23, sdot2(xt, w.w01, 1 << 13)) >> 14;
+                const int iy = sdot2(yb, w.w23, sdot2(yt, w.w01, 1 << 13)) >> 14;
                 ixv[i] = active ? ix : 0;
                 iyv[i] = active ? iy : 0;
             }
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         int s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
         for (int i = 0; i < RUN; i++) {
-            s11 += m24(ixv[i], ixv[i]);
-            s12 += m24(ixv[i], iyv[i]);
-            s22 += m24(iyv[i], iyv[i]);
+            s11 = mad24(ixv[i], ixv[i], s11);
+            s12 = mad24(ixv[i], iyv[i], s12);
+            s22 = mad24(iyv[i], iyv[i], s22);
         }
         const float A11 = wave_sum((float)s11) * FLT_SCALE;
         const float A12 = wave_sum((float)s12) * FLT_SCALE;
@@ -197,6 +202,7 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         D = 1.f / D;
 
         // ---- Gauss-Newton iterations -----------------------------------------------------------
+        const uint8_t *jrow = J.origin + (ptrdiff_t)r * J.pitch + cx; // lane's run at window origin (0,0)
         float nx = ox - halfWin, ny = oy - halfWin;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; j++) {
@@ -206,18 +212,16 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 break;
             }
             w = bilinear_weights(nx - inx, ny - iny);
-            uint32_t t0[2], t1[2];
-            const uint8_t *jb = J.origin + (ptrdiff_t)(iny + r) * J.pitch + (inx + cx);
-            load_bytes<2>(jb, t0);
-            load_bytes<2>(jb + J.pitch, t1);
+            const uint8_t *jb = jrow + ((ptrdiff_t)iny * J.pitch + inx);
+            const Run8 t = load_run8(jb), b = load_run8(jb + J.pitch);
+            int v[RUN];
+            sample_run(t, b, w, v);
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int i = 0; i < RUN; i++) {
-                const int v = m24(byte_at(t0, i), w.w00) + m24(byte_at(t0, i + 1), w.w01) +
-                              m24(byte_at(t1, i), w.w10) + m24(byte_at(t1, i + 1), w.w11);
-                const int diff = descale(v, 14 - 5) - Iv[i];
-                b1 += m24(diff, ixv[i]);
-                b2 += m24(diff, iyv[i]);
+                const int diff = v[i] - Iv[i];
+                b1 = mad24(diff, ixv[i], b1);
+                b2 = mad24(diff, iyv[i], b2);
             }
             const float fb1 = wave_sum((float)b1) * FLT_SCALE;
             const float fb2 = wave_sum((float)b2) * FLT_SCALE;
@@ -241,16 +245,14 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 status = 0;
             } else {
                 w = bilinear_weights(fx - inx, fy - iny);
-                uint32_t t0[2], t1[2];
-                const uint8_t *jb = J.origin + (ptrdiff_t)(iny + r) * J.pitch + (inx + cx);
-                load_bytes<2>(jb, t0);
-                load_bytes<2>(jb + J.pitch, t1);
+                const uint8_t *jb = jrow + ((ptrdiff_t)iny * J.pitch + inx);
+                const Run8 t = load_run8(jb), b = load_run8(jb + J.pitch);
+                int v[RUN];
+                sample_run(t, b, w, v);
                 int e = 0;
 #pragma unroll
                 for (int i = 0; i < RUN; i++) {
-                    const int v = m24(byte_at(t0, i), w.w00) + m24(byte_at(t0, i + 1), w.w01) +
-                                  m24(byte_at(t1, i), w.w10) + m24(byte_at(t1, i + 1), w.w11);
-                    const int diff = descale(v, 14 - 5) - Iv[i];
+                    const int diff = v[i] - Iv[i];
                     e += diff < 0 ? -diff : diff;
                 }
                 if (!active) e = 0;
@@ -285,6 +287,7 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     for (int i = 0; i < n_pairs; i++) {
         if (!slot_ok(ctx, pairs.prev[i]) || !slot_ok(ctx, pairs.next[i])) return KTLVO_ERR_INVALID;
         if (ctx->built[pairs.prev[i]] < 0 || ctx->built[pairs.next[i]] < 0) return KTLVO_ERR_STATE;
+        if (!ctx->deriv_ok[pairs.prev[i]]) return KTLVO_ERR_STATE; // ktlvo_build_pyramid makes the Scharr planes
         max_level = effective_max_level(ctx, pairs.prev[i], pairs.next[i], max_level);
     }
     for (int i = 0; i < n_pairs; i++) // every pair of one launch runs the same level count

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libktlvo_hip.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
-K_PYRDOWN, K_PYRLK, K_CORNER, K_RANSAC = 0, 1, 2, 3
+K_PYRDOWN, K_PYRLK, K_CORNER, K_RANSAC, K_SCHARR = 0, 1, 2, 3, 4
 
 
 class KtlvoError(RuntimeError):

@@ -136,6 +136,33 @@ def test_lk_max_level_3_and_iteration_limits(make_ctx, oracle, klib):
         _lk_compare(go, gs, ge, oo, os_, oe)
 
 
+def test_lk_negative_remainder_weight(make_ctx, oracle, klib):
+    """The fourth bilinear weight is 2^14 minus the three rounded ones and can be -1; points whose
+    sub-pixel fractions trigger that must still match (signed arithmetic in the samplers)."""
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 0.02, 400000).astype(np.float32)
+    b = rng.uniform(0, 0.02, 400000).astype(np.float32)
+    one, s = np.float32(1), np.float32(16384)
+    w = [np.rint((one - a) * (one - b) * s), np.rint(a * (one - b) * s), np.rint((one - a) * b * s)]
+    neg = np.nonzero(s - w[0] - w[1] - w[2] < 0)[0][:500]
+    assert len(neg) == 500
+    W, H = 640, 480
+    img = synth.texture_image(W, H, seed=12)
+    ix = rng.integers(40, W - 40, 500).astype(np.float32)
+    iy = rng.integers(40, H - 40, 500).astype(np.float32)
+    pts = np.stack([ix + a[neg], iy + b[neg]], 1).astype(np.float32)
+    fa = (pts[:, 0] - np.float32(10)) - np.floor(pts[:, 0] - np.float32(10))
+    assert np.abs(fa - a[neg]).max() < 1e-4                  # the fraction survives the float add
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, img)
+    ctx.upload_image(1, img)
+    ctx.build_pyramids([0, 1])
+    go, gs, ge = ctx.pyrlk(0, 1, pts, klib.lk_params(max_level=0))
+    oo, os_, oe = oracle.pyrlk(img, img, pts, max_level=0)
+    _lk_compare(go, gs, ge, oo, os_, oe)
+    assert gs.mean() > 0.9 and (ge[gs == 1] < 0.5).all()     # an unsigned sampler is off by 128 grey levels here
+
+
 def test_lk_full_size_properties(make_ctx):
     """Size-independent properties at the benchmark's size: zero motion maps every trackable point
     onto itself, and forward-backward tracking returns to the start."""
