@@ -187,10 +187,12 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
         SlotList list;
         list.n = n_slots - base < MAX_BATCH ? n_slots - base : MAX_BATCH;
         for (int i = 0; i < list.n; i++) list.s[i] = slots[base + i];
-        ProfScope ps(ctx, KTLVO_K_PYRDOWN);
-        for (int l = 0; l < top; l++) {
-            dim3 grid((ctx->lw[l + 1] + TW - 1) / TW, (ctx->lh[l + 1] + TH - 1) / TH, list.n);
-            hipLaunchKernelGGL(pyr_down_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, l);
+        {
+            ProfScope ps(ctx, KTLVO_K_PYRDOWN);
+            for (int l = 0; l < top; l++) {
+                dim3 grid((ctx->lw[l + 1] + TW - 1) / TW, (ctx->lh[l + 1] + TH - 1) / TH, list.n);
+                hipLaunchKernelGGL(pyr_down_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, l);
+            }
         }
         KTLVO_HIP(ctx, hipGetLastError());
         {

@@ -49,14 +49,23 @@ __device__ __forceinline__ float dpp_add(float v) {
 }
 
 // Sum over the 64 lanes, returned wave-uniform.  Fixed tree, so the result is deterministic.
+// The two cross-row steps are written as asm: v_add_f32_dpp with a row mask leaves the other rows'
+// registers untouched, which is the fused form of "add the broadcast lane, or add 0".  The s_nops
+// are the VALU-write -> DPP-read / readlane wait states, which the compiler does not insert for asm.
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]
     v = dpp_add<0x141, 0xF>(v); // row_half_mirror
     v = dpp_add<0x140, 0xF>(v); // row_mirror: every lane holds its 16-lane row sum
-    v = dpp_add<0x142, 0xA>(v); // row_bcast15 into rows 1 and 3
-    v = dpp_add<0x143, 0xC>(v); // row_bcast31 into rows 2 and 3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    int total;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa\n\t" // rows 1, 3 += lane 15 of rows 0, 2
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc\n\t" // rows 2, 3 += lane 31
+        "s_nop 1\n\t"
+        "v_readlane_b32 %0, %1, 63"
+        : "=s"(total), "+v"(v));
+    return __int_as_float(total);
 }
 
 // a * b + c on 24-bit signed factors (every factor here is below 2^15 in magnitude); written as
@@ -79,27 +88,32 @@ struct Weights {
     uint32_t w01, w23;
 };
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
-    const int w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
-    const int w01 = __float2int_rn(a * (1.f - b) * 16384.f);
-    const int w10 = __float2int_rn((1.f - a) * b * 16384.f);
-    const int w11 = 16384 - w00 - w01 - w10;
+    // OpenCV: iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14), iw10 = cvRound((1-a)*b*2^14).
+    // Scaling by 2^14 is exact, so it can be folded into one factor first; adding 2^23 rounds a
+    // float in [0, 2^23) to the nearest-even integer and leaves it in the low mantissa bits.
+    const float A = 1.f - a, B = (1.f - b) * 16384.f, bs = b * 16384.f;
+    const uint32_t m00 = __float_as_uint(A * B + 8388608.f);
+    const uint32_t m01 = __float_as_uint(a * B + 8388608.f);
+    const uint32_t m10 = __float_as_uint(A * bs + 8388608.f);
+    // 16384 - iw00 - iw01 - iw10 in the low 16 bits (the 0x4B000000 exponent fields cancel mod 2^32)
+    const uint32_t m11 = (16384u + 3u * 0x4B000000u) - (m00 + m01 + m10);
     Weights w;
-    w.w01 = (uint32_t)w00 | ((uint32_t)w01 << 16);
-    w.w23 = (uint32_t)w10 | ((uint32_t)w11 << 16); // w10 >= 0, so no sign bits leak into the high half
+    w.w01 = __builtin_amdgcn_perm(m01, m00, 0x05040100u);
+    w.w23 = __builtin_amdgcn_perm(m11, m10, 0x05040100u);
     return w;
 }
 
-// Eight consecutive bytes starting at an arbitrary byte address, as two dwords.
+// Eight consecutive bytes starting at byte offset `off` of a plane whose base is dword aligned.
 struct Run8 {
     uint32_t lo, hi;
 };
-__device__ __forceinline__ Run8 load_run8(const uint8_t *p) {
-    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
-    gptr32 q = (gptr32)(p - sh);
+__device__ __forceinline__ Run8 load_run8(const uint8_t *base, uint32_t off) {
+    typedef const __attribute__((address_space(1))) uint8_t *gptr8;
+    gptr32 q = (gptr32)((gptr8)base + (off & ~3u));
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
     Run8 r;
-    r.lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    r.hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    r.lo = __builtin_amdgcn_alignbyte(d1, d0, off & 3u);
+    r.hi = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
     return r;
 }
 // bytes i and i+1 of a run, zero-extended into a u16 pair
@@ -108,10 +122,13 @@ __device__ __forceinline__ uint32_t pix_pair(const Run8 &r) {
     constexpr uint32_t sel = 0x0c000c00u | (uint32_t)I | ((uint32_t)(I + 1) << 16);
     return __builtin_amdgcn_perm(r.hi, r.lo, sel);
 }
-// the seven fixed-point bilinear samples (scaled by 32) of a lane's run
-__device__ __forceinline__ void sample_run(const Run8 &t, const Run8 &b, const Weights &w, int (&v)[7]) {
+// The seven fixed-point bilinear samples (scaled by 32) of a lane's run: v[i] = CV_DESCALE(sum, 9)
+// + (acc0[i] - 256) / 512.  With acc0 = 256 this is the sample itself; with acc0 = 256 - 512 * I it is
+// sample - I at no extra cost (the subtrahend is a multiple of 2^9, so it commutes with the shift).
+__device__ __forceinline__ void sample_run(const Run8 &t, const Run8 &b, const Weights &w, const int (&acc0)[7],
+                                           int (&v)[7]) {
     // signed dot: the remainder weight w11 can be -1 when the three rounded weights sum to 16385
-#define KTLVO_SAMPLE(I) v[I] = sdot2(pix_pair<I>(b), w.w23, sdot2(pix_pair<I>(t), w.w01, 256)) >> 9
+#define KTLVO_SAMPLE(I) v[I] = sdot2(pix_pair<I>(b), w.w23, sdot2(pix_pair<I>(t), w.w01, acc0[I])) >> 9
     KTLVO_SAMPLE(0); KTLVO_SAMPLE(1); KTLVO_SAMPLE(2); KTLVO_SAMPLE(3); KTLVO_SAMPLE(4); KTLVO_SAMPLE(5); KTLVO_SAMPLE(6);
 #undef KTLVO_SAMPLE
 }
@@ -119,9 +136,11 @@ __device__ __forceinline__ void sample_run(const Run8 &t, const Run8 &b, const W
 constexpr int WIN = 21;
 constexpr int RUN = 7;
 
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = uniform((int)(threadIdx.x >> 6));
     const int f = blockIdx.x * 4 + wave;
     const int n = a.d_n ? min(*a.d_n, a.n_per_pair) : a.n_per_pair;
     if (f >= n) return;
@@ -146,29 +165,44 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
     for (int level = a.max_level; level >= 0; --level) {
         const LevelDesc I = SP.lv[level];
         const LevelDesc J = SN.lv[level];
+        const int pitch = I.pitch; // both slots share the level geometry
+        // plane bases (element (-PAD,-PAD)) and this lane's run offset from there: offsets stay >= 0
+        const int org = PAD * pitch + PAD;
+        const uint8_t *Ibase = I.origin - org, *Jbase = J.origin - org;
+        const uint32_t *Dbase = I.dorigin - org;
+        const uint32_t lane_off = (uint32_t)(org + r * pitch + cx);
+
         const float sc = __int_as_float((127 - level) << 23); // (float)(1./(1 << level))
         float px = ppx * sc, py = ppy * sc;
         if (level == a.max_level) { ox = px; oy = py; }
         else { ox = ox * 2.f; oy = oy * 2.f; }
 
         px -= halfWin; py -= halfWin;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
         if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
             if (level == 0) { status = 0; errv = 0.f; }
             continue;
         }
-        Weights w = bilinear_weights(px - ipx, py - ipy);
+        Weights w = bilinear_weights(px - (float)ipx, py - (float)ipy);
 
         // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
-        int Iv[RUN], ixv[RUN], iyv[RUN];
+        int Ineg[RUN], ixv[RUN], iyv[RUN]; // Ineg = 256 - 512 * I: accumulator start of the mismatch samples
         {
-            const ptrdiff_t e0 = (ptrdiff_t)(ipy + r) * I.pitch + (ipx + cx);
-            const Run8 t = load_run8(I.origin + e0), b = load_run8(I.origin + e0 + I.pitch);
-            gptr32 dt = (gptr32)(I.dorigin + e0), db = (gptr32)(I.dorigin + e0 + I.pitch);
+            const uint32_t e0 = lane_off + (uint32_t)(ipy * pitch + ipx);
+            const Run8 t = load_run8(Ibase, e0), b = load_run8(Ibase, e0 + pitch);
+            // the idle lane reads the plane's zero frame, so its derivatives (and all its sums) are 0
+            const uint32_t ed = active ? e0 : 0u;
+            gptr32 dt = (gptr32)Dbase + ed, db = (gptr32)Dbase + (ed + pitch);
             uint32_t d0[RUN + 1], d1[RUN + 1];
 #pragma unroll
             for (int k = 0; k <= RUN; k++) { d0[k] = dt[k]; d1[k] = db[k]; }
-            sample_run(t, b, w, Iv);
+            {
+                const int round9[RUN] = {256, 256, 256, 256, 256, 256, 256};
+                int Iv[RUN];
+                sample_run(t, b, w, round9, Iv);
+#pragma unroll
+                for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
+            }
 #pragma unroll
             for (int i = 0; i < RUN; i++) {
                 // (dx_i, dx_i+1) and (dy_i, dy_i+1) as int16 pairs
@@ -176,10 +210,8 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 const uint32_t yt = __builtin_amdgcn_perm(d0[i + 1], d0[i], 0x07060302u);
                 const uint32_t xb = __builtin_amdgcn_perm(d1[i + 1], d1[i], 0x05040100u);
                 const uint32_t yb = __builtin_amdgcn_perm(d1[i + 1], d1[i], 0x07060302u);
-                const int ix = sdot2(xb, w.w23, sdot2(xt, w.w01, 1 << 13)) >> 14;
-                const int iy = sdot2(yb, w.w23, sdot2(yt, w.w01, 1 << 13)) >> 14;
-                ixv[i] = active ? ix : 0;
-                iyv[i] = active ? iy : 0;
+                ixv[i] = sdot2(xb, w.w23, sdot2(xt, w.w01, 1 << 13)) >> 14;
+                iyv[i] = sdot2(yb, w.w23, sdot2(yt, w.w01, 1 << 13)) >> 14;
             }
         }
         int s11 = 0, s12 = 0, s22 = 0;
@@ -202,26 +234,24 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         D = 1.f / D;
 
         // ---- Gauss-Newton iterations -----------------------------------------------------------
-        const uint8_t *jrow = J.origin + (ptrdiff_t)r * J.pitch + cx; // lane's run at window origin (0,0)
         float nx = ox - halfWin, ny = oy - halfWin;
         float pdx = 0.f, pdy = 0.f;
         for (int j = 0; j < a.max_count; j++) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            const int inx = uniform((int)floorf(nx)), iny = uniform((int)floorf(ny));
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 if (level == 0) status = 0;
                 break;
             }
-            w = bilinear_weights(nx - inx, ny - iny);
-            const uint8_t *jb = jrow + ((ptrdiff_t)iny * J.pitch + inx);
-            const Run8 t = load_run8(jb), b = load_run8(jb + J.pitch);
-            int v[RUN];
-            sample_run(t, b, w, v);
+            w = bilinear_weights(nx - (float)inx, ny - (float)iny);
+            const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
+            const Run8 t = load_run8(Jbase, e0), b = load_run8(Jbase, e0 + pitch);
+            int diff[RUN];
+            sample_run(t, b, w, Ineg, diff);
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int i = 0; i < RUN; i++) {
-                const int diff = v[i] - Iv[i];
-                b1 = mad24(diff, ixv[i], b1);
-                b2 = mad24(diff, iyv[i], b2);
+                b1 = mad24(diff[i], ixv[i], b1);
+                b2 = mad24(diff[i], iyv[i], b2);
             }
             const float fb1 = wave_sum((float)b1) * FLT_SCALE;
             const float fb2 = wave_sum((float)b2) * FLT_SCALE;
@@ -230,7 +260,9 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
             nx += dx; ny += dy;
             ox = nx + halfWin; oy = ny + halfWin;
             if ((double)dx * dx + (double)dy * dy <= a.eps_sq) break;
-            if (j > 0 && fabsf(dx + pdx) < 0.01 && fabsf(dy + pdy) < 0.01) {
+            // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
+            // so "<= 0.01f" is the same predicate without leaving single precision
+            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
                 ox -= dx * 0.5f; oy -= dy * 0.5f;
                 break;
             }
@@ -240,21 +272,18 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         // ---- final error (level 0 only) ------------------------------------------------------
         if (level == 0 && status) {
             const float fx = ox - halfWin, fy = oy - halfWin;
-            const int inx = (int)floorf(fx), iny = (int)floorf(fy);
+            const int inx = uniform((int)floorf(fx)), iny = uniform((int)floorf(fy));
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 status = 0;
             } else {
-                w = bilinear_weights(fx - inx, fy - iny);
-                const uint8_t *jb = jrow + ((ptrdiff_t)iny * J.pitch + inx);
-                const Run8 t = load_run8(jb), b = load_run8(jb + J.pitch);
-                int v[RUN];
-                sample_run(t, b, w, v);
+                w = bilinear_weights(fx - (float)inx, fy - (float)iny);
+                const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
+                const Run8 t = load_run8(Jbase, e0), b = load_run8(Jbase, e0 + pitch);
+                int diff[RUN];
+                sample_run(t, b, w, Ineg, diff);
                 int e = 0;
 #pragma unroll
-                for (int i = 0; i < RUN; i++) {
-                    const int diff = v[i] - Iv[i];
-                    e += diff < 0 ? -diff : diff;
-                }
+                for (int i = 0; i < RUN; i++) e += diff[i] < 0 ? -diff[i] : diff[i];
                 if (!active) e = 0;
                 errv = wave_sum((float)e) * 1.f / (float)(32 * WIN * WIN);
             }
