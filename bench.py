@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from slam_amd import lib as K  # noqa: E402  (raises if libktlvo_hip.so is missing: no fallback)
-from slam_amd import synth  # noqa: E402
+from slam_amd import shard, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling
@@ -120,7 +120,7 @@ def main():
     pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
 
     # ---- synthetic input: one sequence per rank -----------------------------------------------
-    scene = synth.CorridorScene(W, H, seed=a.seed + rank)
+    scene = synth.CorridorScene(W, H, seed=shard.rank_seed(a.seed, rank))
     frames = [scene.render(f) for f in range(P + 1)]
     cfg = K.default_config(width=W, height=H, num_slots=P + 1, max_level=a.max_level, max_points=max(NF, 1024),
                            cx=scene.cx, cy=scene.cy)
@@ -172,22 +172,14 @@ def main():
     ctx.profile_enable(False)
 
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rec = torch.tensor([float(P * NF), float(tracked), float(P), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
                        dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(gathered, rec)             # the only collective: fixed-size per-rank statistics
-        recs = torch.stack(gathered).cpu().numpy()
-    else:
-        recs = rec.cpu().numpy()[None]
-    t_max = float(el.item())
+    t_max = shard.max_over_ranks(elapsed, dev, world)
+    recs = shard.gather_records(rec, world)        # the only collective: fixed-size per-rank statistics
 
     if rank == 0:
-        total_tracked = float(recs[:, 1].sum())
-        total_in = float(recs[:, 0].sum())
-        value = total_tracked * a.steps / t_max
+        agg = shard.aggregate(recs, a.steps, t_max)
+        total_tracked, total_in, value = agg["tracked_per_step"], agg["features_in_per_step"], agg["value"]
         bpf = lk_bytes_per_feature(levels)
         k3_avg_s = (k3_ms / max(k3_n, 1)) * 1e-3
         feats_per_launch = P * NF
@@ -218,7 +210,7 @@ def main():
                 "per_gpu_sequence": "corridor seed 0x%X + rank" % a.seed,
                 "features_in_per_step": total_in,
                 "tracked_per_step": total_tracked,
-                "pairs_per_s": float(recs[:, 2].sum()) * a.steps / t_max,
+                "pairs_per_s": agg["pairs_per_s"],
             },
             "roofline": {
                 "bound": "hbm",

@@ -27,6 +27,8 @@ struct LkArgs {
     uint8_t *status;
     float *err;
     int n_per_pair;
+    int n_pairs;
+    int blocks_per_pair; // ceil(n_per_pair / 4)
     int max_level;
     int max_count;
     double eps_sq;
@@ -75,8 +77,13 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// a.lo * b.lo + a.hi * b.hi + c on int16 pairs.  Written as asm to get the three-address VOP3P
+// form: the builtin is selected as v_dot2c (dst == accumulator), which costs a v_mov whenever the
+// accumulator input has to survive (it always does here: it is the template).
 __device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
 }
 __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
@@ -141,10 +148,16 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = uniform((int)(threadIdx.x >> 6));
-    const int f = blockIdx.x * 4 + wave;
+    // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each with its
+    // own 4 MiB L2.  All workgroups of a frame pair are therefore given block ids of one residue
+    // class mod 8, so a pair's two pyramids are fetched into one L2 instead of eight.  This is a
+    // locality hint only; any placement gives the same results.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pair = xcd + 8 * (q / a.blocks_per_pair);
+    if (pair >= a.n_pairs) return;
+    const int f = (q % a.blocks_per_pair) * 4 + wave;
     const int n = a.d_n ? min(*a.d_n, a.n_per_pair) : a.n_per_pair;
     if (f >= n) return;
-    const int pair = blockIdx.y;
     const SlotDesc &SP = a.slots[a.pairs.prev[pair]];
     const SlotDesc &SN = a.slots[a.pairs.next[pair]];
     const size_t gp = (size_t)a.prev_off[pair] + f;
@@ -334,7 +347,10 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     a.d_n = d_n;
     a.pairs = pairs;
     for (int i = 0; i < n_pairs; i++) { a.prev_off[i] = prev_off[i]; a.next_off[i] = next_off[i]; }
-    dim3 grid((n_per_pair + 3) / 4, n_pairs);
+    a.n_pairs = n_pairs;
+    a.blocks_per_pair = (n_per_pair + 3) / 4;
+    // 8 residue classes x ceil(n_pairs / 8) pairs each x blocks per pair
+    dim3 grid((unsigned)(8 * ((n_pairs + 7) / 8) * a.blocks_per_pair));
     ProfScope ps(ctx, KTLVO_K_PYRLK);
     hipLaunchKernelGGL(pyrlk_track_w21, grid, dim3(256), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());

@@ -1,0 +1,59 @@
+"""Multi-GPU partitioning of the feature-tracking path.
+
+Features, frame pairs and sequences are independent, so work is sharded across ranks with no
+data-path collective; the only exchange is one all_gather of a fixed-size per-rank record
+(statistics and, for sequence runs, the 4x4 poses) at the end.  Backend "nccl" is RCCL on ROCm;
+"gloo" runs the same code on CPU for tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RECORD_FIELDS = ("features_in", "tracked", "pairs", "k3_ms", "k3_launches", "k1_ms", "k1_launches", "elapsed_s")
+
+
+def rank_seed(base_seed, rank):
+    """Each rank renders its own sequence: seed + rank (one sequence per GPU)."""
+    return (base_seed + rank) & 0xFFFFFFFF
+
+
+def shard_round_robin(n_items, rank, world):
+    """Indices of the items (frame pairs, sequences) owned by `rank`."""
+    return list(range(rank, n_items, world))
+
+
+def gather_records(rec, world):
+    """all_gather of one fixed-size float64 record per rank -> array [world, len(rec)]."""
+    if world == 1:
+        return rec.detach().cpu().numpy()[None].copy()
+    out = [torch.zeros_like(rec) for _ in range(world)]
+    dist.all_gather(out, rec)
+    return torch.stack(out).cpu().numpy()
+
+
+def gather_trajectories(poses, world):
+    """poses: float32 [frames, 16] on this rank -> [world, frames, 16] (same frame count everywhere)."""
+    if world == 1:
+        return poses.detach().cpu().numpy()[None].copy()
+    out = [torch.zeros_like(poses) for _ in range(world)]
+    dist.all_gather(out, poses)
+    return torch.stack(out).cpu().numpy()
+
+
+def max_over_ranks(value, device, world):
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate(recs, steps, t_max):
+    """Whole-job numbers from the gathered records (rank 0 prints these)."""
+    recs = np.asarray(recs, dtype=np.float64)
+    total_tracked = float(recs[:, 1].sum())
+    return {
+        "features_in_per_step": float(recs[:, 0].sum()),
+        "tracked_per_step": total_tracked,
+        "value": total_tracked * steps / t_max,
+        "pairs_per_s": float(recs[:, 2].sum()) * steps / t_max,
+    }

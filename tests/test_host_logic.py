@@ -1,0 +1,92 @@
+"""CPU tests of the host-side logic: synthetic data generator, work partitioning and the N > 1
+exchange (gloo, world size 2) that bench.py runs over RCCL on the GPUs."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from slam_amd import shard, synth
+
+
+def test_texture_and_scene_are_deterministic():
+    a1 = synth.texture_image(160, 120, seed=3, dx=0.25, dy=-0.5)
+    a2 = synth.texture_image(160, 120, seed=3, dx=0.25, dy=-0.5)
+    assert np.array_equal(a1, a2) and a1.dtype == np.uint8 and 20 < a1.std() < 70
+    assert not np.array_equal(a1, synth.texture_image(160, 120, seed=4, dx=0.25, dy=-0.5))
+    s = synth.CorridorScene(320, 96, seed=9)
+    l1, r1 = s.stereo_pair(2)
+    l2, r2 = synth.CorridorScene(320, 96, seed=9).stereo_pair(2)
+    assert np.array_equal(l1, l2) and np.array_equal(r1, r2) and not np.array_equal(l1, r1)
+
+
+def test_scene_geometry_matches_its_ground_truth():
+    s = synth.CorridorScene(1241, 376, seed=0x5EED0001)
+    assert abs(s.bf - 0.5461 * 707.0912) < 1e-9 and abs(s.cx - (601.8873 - 0.5)) < 1e-9
+    img, depth = s.render(0, with_depth=True, noise=False)
+    assert depth.min() > 0 and depth[300, 620] < depth[200, 620]          # ground plane recedes upwards
+    # a ground pixel seen by the left camera reappears in the right image shifted by bf / depth
+    v, u = 330, 500
+    d = s.bf / depth[v, u]
+    right = s.render(0, right=True, noise=False)
+    patch = img[v - 4:v + 5, u - 4:u + 5].astype(np.int32)
+    best = min(range(-3, 4), key=lambda k: np.abs(
+        right[v - 4:v + 5, int(round(u - d)) + k - 4:int(round(u - d)) + k + 5].astype(np.int32) - patch).sum())
+    assert abs(best) <= 1
+    T = s.relative_pose(0, 1)
+    assert abs(T[2, 3] + 0.8) < 0.05 and np.abs(T[:3, :3] @ T[:3, :3].T - np.eye(3)).max() < 1e-12
+
+
+def test_partitioning_helpers():
+    assert shard.shard_round_robin(10, 1, 4) == [1, 5, 9]
+    got = sorted(i for r in range(8) for i in shard.shard_round_robin(64, r, 8))
+    assert got == list(range(64))
+    assert shard.rank_seed(0x5EED0010, 3) == 0x5EED0013
+    recs = np.array([[100, 90, 2, 1, 1, 1, 1, 0.5], [100, 80, 2, 1, 1, 1, 1, 0.6]])
+    agg = shard.aggregate(recs, steps=3, t_max=0.6)
+    assert agg["tracked_per_step"] == 170 and abs(agg["value"] - 170 * 3 / 0.6) < 1e-9
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    rec = torch.tensor([2000.0 * (rank + 1), 1900.0 + rank, 32.0, 0.5, 20, 0.04, 20, 0.1 + 0.05 * rank],
+                       dtype=torch.float64)
+    recs = shard.gather_records(rec, world)
+    t_max = shard.max_over_ranks(0.1 + 0.05 * rank, dev, world)
+    poses = torch.full((5, 16), float(rank), dtype=torch.float32)
+    traj = shard.gather_trajectories(poses, world)
+    dist.barrier()
+    if rank == 0:
+        q.put((recs, t_max, traj))
+    dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    recs, t_max, traj = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert recs.shape == (2, 8)
+    assert list(recs[:, 0]) == [2000.0, 4000.0] and list(recs[:, 1]) == [1900.0, 1901.0]
+    assert abs(t_max - 0.15) < 1e-12                                   # max over ranks, as the bench reports
+    assert traj.shape == (2, 5, 16) and (traj[0] == 0).all() and (traj[1] == 1).all()
+    # gathered results equal what two single-process runs produce
+    single = [shard.gather_records(torch.tensor(recs[r]), 1)[0] for r in range(2)]
+    assert np.array_equal(np.stack(single), recs)
