@@ -56,6 +56,22 @@ def pyramid_bytes(w, h, max_level, win=WIN):
     return total, levels
 
 
+def measured_traffic(kernel, waves_per_launch):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary
+    (profiles/r*_pmc_summary.json, written by profiles/summarize_pmc.py from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE
+    doubling applied).  None if no summary matches this launch shape."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            e = json.load(open(path)).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if e and "hbm_bytes_per_launch" in e and int(e.get("SQ_WAVES", -1)) == int(waves_per_launch):
+            return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +204,7 @@ def main():
         for _ in range(levels):
             lv_bytes += w_ * h_
             w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
+        traffic, traffic_src = measured_traffic("pyrlk_track_w21", feats_per_launch)
         out = {
             "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
             "value": value,
@@ -220,7 +237,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "bytes_model_per_feature": bpf,
                 # compulsory-unique traffic of one pair: both pyramids read once + point I/O
                 "bytes_floor_per_feature": (2 * lv_bytes + 29 * NF) / NF,

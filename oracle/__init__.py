@@ -74,6 +74,8 @@ _lib.orc_pyramid_level_copy.argtypes = [C.c_void_p, C.c_int, _u8p]
 _lib.orc_pyramid_deriv_copy.argtypes = [C.c_void_p, C.c_int, _i16p]
 _lib.orc_pyrlk.argtypes = [C.c_void_p, C.c_void_p, _f32p, C.c_int, _f32p, _u8p, _f32p, C.c_int, C.c_int, C.c_int,
                            C.c_double, C.c_double, C.c_int]
+_lib.orc_set_iter_log.argtypes = [C.c_void_p, C.c_int]
+_lib.orc_set_iter_log.restype = None
 _lib.orc_corner_response.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, _f32p]
 _lib.orc_good_features.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -176,6 +178,18 @@ def pyrlk(prev, nxt, pts, win=21, max_level=4, max_count=30, epsilon=0.01, min_e
     if rc != 0:
         raise RuntimeError("orc_pyrlk rc=%d" % rc)
     return out, status, err
+
+
+def lk_iterations(prev, nxt, pts, max_level=4, **kw):
+    """Iterations per (level, point) of a single-threaded pyrlk call: uint8 [levels, n]."""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    log = np.zeros((max_level + 1, pts.shape[0]), np.uint8)
+    _lib.orc_set_iter_log(log.ctypes.data, pts.shape[0])
+    try:
+        out = pyrlk(prev, nxt, pts, max_level=max_level, nthreads=1, **kw)
+    finally:
+        _lib.orc_set_iter_log(None, 0)
+    return log, out
 
 
 def corner_response(img, roi=None, use_harris=True, k=0.0):

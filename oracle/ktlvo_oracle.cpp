@@ -164,6 +164,10 @@ extern "C" int orc_pyramid_deriv_copy(const orc_pyramid *p, int level, int16_t *
     return 0;
 }
 
+static uint8_t *g_iter_log = nullptr; /* optional diagnostics: iterations per (level, point) */
+static int g_iter_log_n = 0;
+extern "C" void orc_set_iter_log(uint8_t *buf, int n_points) { g_iter_log = buf; g_iter_log_n = n_points; }
+
 namespace {
 
 /* LKTrackerInvoker::operator() (scalar path: float accumulators) for points [i0,i1) of one level. */
@@ -229,7 +233,9 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
 
         nx -= halfWin; ny -= halfWin;
         float pdx = 0, pdy = 0;
+        int jcount = 0;
         for (int j = 0; j < maxCount; j++) {
+            jcount = j + 1;
             int inx = cv_floor(nx), iny = cv_floor(ny);
             if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
                 if (level == 0) status[pt] = 0;
@@ -265,6 +271,7 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
             }
             pdx = dx; pdy = dy;
         }
+        if (g_iter_log && pt < g_iter_log_n) g_iter_log[(size_t)level * g_iter_log_n + pt] = (uint8_t)jcount;
 
         if (status[pt] && level == 0) {
             float fx = nextPts[2 * pt] - halfWin, fy = nextPts[2 * pt + 1] - halfWin;

@@ -52,6 +52,10 @@ int orc_pyrlk(const orc_pyramid *prev, const orc_pyramid *next, const float *pre
               float *next_xy, uint8_t *status, float *err, int win, int max_level,
               int max_count, double epsilon, double min_eig_thr, int nthreads);
 
+/* Diagnostics: while set, orc_pyrlk records the Gauss-Newton iteration count of every point and
+ * level into buf[level * n_points + point] (single-threaded calls only). NULL switches it off. */
+void orc_set_iter_log(uint8_t *buf, int n_points);
+
 /* cornerHarris / cornerMinEigenVal (blockSize 3, Sobel 3, 8-bit) on the ROI (rx,ry,rw,rh) of
  * a parent image; Sobel reads parent pixels beyond the ROI (reflect-101 only at the parent's
  * edges), the 3x3 box sum reflects at the ROI's own edges. out is rw*rh floats. */

@@ -370,3 +370,37 @@ def test_solve_pnp_ransac_matches_oracle(make_ctx, oracle):
     assert not r["ok"]
     r = ctx.solve_pnp_ransac(g["X3"][:0], g["x2"][:0])
     assert not r["ok"]
+
+
+# ---------------------------------------------------------------- full benchmark sizes -----------
+@pytest.mark.parametrize("size,ncorners,min_dist", [((1920, 1080), 8000, 5.0), ((3840, 2160), 16384, 8.0)])
+def test_full_size_frames(make_ctx, oracle, klib, size, ncorners, min_dist):
+    """BASELINE configs 3 and 5 shapes: whole-frame Shi-Tomasi detection and LK at 1080p / 4K.
+    Direct parity with the oracle plus size-independent properties (zero motion is the identity,
+    a known global shift is recovered, forward-backward returns to the start)."""
+    W, H = size
+    shift = (2.5, -1.25)
+    a, b = synth.texture_pair(W, H, 5, shift[0], shift[1], periods=(32.0, 8.0))
+    ctx = make_ctx(width=W, height=H, max_points=ncorners, num_slots=3)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.upload_image(2, a)
+    ctx.build_pyramids([0, 1, 2])
+    pa, pb = oracle.Pyramid(a), oracle.Pyramid(b, with_deriv=False)
+    assert ctx.pyramid_levels(0) == pa.max_level == 4
+    for l in (1, 4):
+        assert np.array_equal(ctx.download_level(0, l), pa.level(l))
+    (xy, resp), = ctx.detect_gftt(0, [(0, 0, W, H)], klib.gftt_params(ncorners, 0.01, min_dist, 3, 0, 0.0))
+    oxy, oresp = oracle.good_features(a, None, ncorners, 0.01, min_dist, False, 0.0)
+    assert len(xy) == ncorners and np.array_equal(xy, oxy) and np.array_equal(resp, oresp)
+    go, gs, ge = ctx.pyrlk(0, 1, xy)
+    oo, os_, oe = oracle.pyrlk(pa, pb, xy, nthreads=8)
+    both = _lk_compare(go, gs, ge, oo, os_, oe)
+    assert both.mean() > 0.95
+    e = np.abs(go - xy - np.array(shift, np.float32))[both]
+    assert np.median(e) < 0.02
+    z, zs, _ = ctx.pyrlk(0, 2, xy)                                  # zero motion
+    assert (np.abs(z - xy)[zs == 1] < 1e-3).all()
+    r, rs, _ = ctx.pyrlk(1, 0, go)                                   # forward-backward
+    ok = (gs == 1) & (rs == 1)
+    assert np.median(np.abs(r - xy)[ok]) < 0.02
