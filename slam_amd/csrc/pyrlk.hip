@@ -90,9 +90,12 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 // Bilinear weights as OpenCV forms them: cvRound of float products scaled by 2^14, the fourth
-// as the remainder.  w01 = top pair (w00 | w01 << 16), w23 = bottom pair (w10 | w11 << 16).
+// as the remainder.  They are packed per COLUMN: wl = (w00 | w10 << 16) weighs the left pixel of
+// the top and bottom row, wr = (w01 | w11 << 16) the right one.  A sample is then
+// dot2(col[i], wl) + dot2(col[i+1], wr) with col[k] = (top[k], bottom[k]), so one vertical pixel
+// pair serves two neighbouring samples (8 v_perm per run instead of 14).
 struct Weights {
-    uint32_t w01, w23;
+    uint32_t wl, wr;
 };
 __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     // OpenCV: iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14), iw10 = cvRound((1-a)*b*2^14).
@@ -105,8 +108,8 @@ __device__ __forceinline__ Weights bilinear_weights(float a, float b) {
     // 16384 - iw00 - iw01 - iw10 in the low 16 bits (the 0x4B000000 exponent fields cancel mod 2^32)
     const uint32_t m11 = (16384u + 3u * 0x4B000000u) - (m00 + m01 + m10);
     Weights w;
-    w.w01 = __builtin_amdgcn_perm(m01, m00, 0x05040100u);
-    w.w23 = __builtin_amdgcn_perm(m11, m10, 0x05040100u);
+    w.wl = __builtin_amdgcn_perm(m10, m00, 0x05040100u);
+    w.wr = __builtin_amdgcn_perm(m11, m01, 0x05040100u);
     return w;
 }
 
@@ -123,21 +126,27 @@ __device__ __forceinline__ Run8 load_run8(const uint8_t *base, uint32_t off) {
     r.hi = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
     return r;
 }
-// bytes i and i+1 of a run, zero-extended into a u16 pair
-template <int I>
-__device__ __forceinline__ uint32_t pix_pair(const Run8 &r) {
-    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)I | ((uint32_t)(I + 1) << 16);
-    return __builtin_amdgcn_perm(r.hi, r.lo, sel);
+// byte K of the top run and byte K of the bottom run, zero-extended into an int16 pair
+template <int K>
+__device__ __forceinline__ uint32_t col_pair(const Run8 &t, const Run8 &b) {
+    constexpr uint32_t sel = 0x0c000c00u | (uint32_t)(K & 3) | ((uint32_t)((K & 3) + 4) << 16);
+    return K < 4 ? __builtin_amdgcn_perm(b.lo, t.lo, sel) : __builtin_amdgcn_perm(b.hi, t.hi, sel);
 }
 // The seven fixed-point bilinear samples (scaled by 32) of a lane's run: v[i] = CV_DESCALE(sum, 9)
 // + (acc0[i] - 256) / 512.  With acc0 = 256 this is the sample itself; with acc0 = 256 - 512 * I it is
 // sample - I at no extra cost (the subtrahend is a multiple of 2^9, so it commutes with the shift).
+// Signed dots: the remainder weight w11 can be -1 when the three rounded weights sum to 16385.
 __device__ __forceinline__ void sample_run(const Run8 &t, const Run8 &b, const Weights &w, const int (&acc0)[7],
                                            int (&v)[7]) {
-    // signed dot: the remainder weight w11 can be -1 when the three rounded weights sum to 16385
-#define KTLVO_SAMPLE(I) v[I] = sdot2(pix_pair<I>(b), w.w23, sdot2(pix_pair<I>(t), w.w01, acc0[I])) >> 9
-    KTLVO_SAMPLE(0); KTLVO_SAMPLE(1); KTLVO_SAMPLE(2); KTLVO_SAMPLE(3); KTLVO_SAMPLE(4); KTLVO_SAMPLE(5); KTLVO_SAMPLE(6);
-#undef KTLVO_SAMPLE
+    const uint32_t c0 = col_pair<0>(t, b), c1 = col_pair<1>(t, b), c2 = col_pair<2>(t, b), c3 = col_pair<3>(t, b);
+    const uint32_t c4 = col_pair<4>(t, b), c5 = col_pair<5>(t, b), c6 = col_pair<6>(t, b), c7 = col_pair<7>(t, b);
+    v[0] = sdot2(c1, w.wr, sdot2(c0, w.wl, acc0[0])) >> 9;
+    v[1] = sdot2(c2, w.wr, sdot2(c1, w.wl, acc0[1])) >> 9;
+    v[2] = sdot2(c3, w.wr, sdot2(c2, w.wl, acc0[2])) >> 9;
+    v[3] = sdot2(c4, w.wr, sdot2(c3, w.wl, acc0[3])) >> 9;
+    v[4] = sdot2(c5, w.wr, sdot2(c4, w.wl, acc0[4])) >> 9;
+    v[5] = sdot2(c6, w.wr, sdot2(c5, w.wl, acc0[5])) >> 9;
+    v[6] = sdot2(c7, w.wr, sdot2(c6, w.wl, acc0[6])) >> 9;
 }
 
 constexpr int WIN = 21;
@@ -216,15 +225,17 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
 #pragma unroll
                 for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
             }
+            // column pairs (top, bottom) of dx and of dy; each serves two neighbouring samples
+            uint32_t cxp[RUN + 1], cyp[RUN + 1];
+#pragma unroll
+            for (int k = 0; k <= RUN; k++) {
+                cxp[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x05040100u);
+                cyp[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
+            }
 #pragma unroll
             for (int i = 0; i < RUN; i++) {
-                // (dx_i, dx_i+1) and (dy_i, dy_i+1) as int16 pairs
-                const uint32_t xt = __builtin_amdgcn_perm(d0[i + 1], d0[i], 0x05040100u);
-                const uint32_t yt = __builtin_amdgcn_perm(d0[i + 1], d0[i], 0x07060302u);
-                const uint32_t xb = __builtin_amdgcn_perm(d1[i + 1], d1[i], 0x05040100u);
-                const uint32_t yb = __builtin_amdgcn_perm(d1[i + 1], d1[i], 0x07060302u);
-                ixv[i] = sdot2(xb, w.w23, sdot2(xt, w.w01, 1 << 13)) >> 14;
-                iyv[i] = sdot2(yb, w.w23, sdot2(yt, w.w01, 1 << 13)) >> 14;
+                ixv[i] = sdot2(cxp[i + 1], w.wr, sdot2(cxp[i], w.wl, 1 << 13)) >> 14;
+                iyv[i] = sdot2(cyp[i + 1], w.wr, sdot2(cyp[i], w.wl, 1 << 13)) >> 14;
             }
         }
         int s11 = 0, s12 = 0, s22 = 0;
