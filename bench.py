@@ -126,10 +126,18 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # KTLVO_BENCH_REHEARSAL=1: every rank uses GPU 0 and gloo, to exercise the N > 1 code path on
+    # a one-GPU box (RCCL refuses two ranks on one device).  Never set for a measurement.
+    rehearsal = os.environ.get("KTLVO_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H, P, NF = a.width, a.height, a.pairs, a.features
     assert 1 <= P <= 63
@@ -217,7 +225,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8 -> i32 fixed point, f32 sums",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if rehearsal else ""),
             "config": {
                 "workload": "BASELINE configs[1]: %dx%d gray frame-pair stream, %d Shi-Tomasi corners/frame, "
                             "maxLevel=%d (%d pyramid levels), 21x21 window, 30 it / eps 0.01" % (W, H, NF, a.max_level,

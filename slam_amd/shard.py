@@ -22,10 +22,16 @@ def shard_round_robin(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def _collective_tensor(t):
+    """RCCL ("nccl") exchanges device tensors; gloo (CPU tests, rehearsals) wants host tensors."""
+    return t.cpu() if dist.get_backend() == "gloo" else t
+
+
 def gather_records(rec, world):
     """all_gather of one fixed-size float64 record per rank -> array [world, len(rec)]."""
     if world == 1:
         return rec.detach().cpu().numpy()[None].copy()
+    rec = _collective_tensor(rec)
     out = [torch.zeros_like(rec) for _ in range(world)]
     dist.all_gather(out, rec)
     return torch.stack(out).cpu().numpy()
@@ -35,6 +41,7 @@ def gather_trajectories(poses, world):
     """poses: float32 [frames, 16] on this rank -> [world, frames, 16] (same frame count everywhere)."""
     if world == 1:
         return poses.detach().cpu().numpy()[None].copy()
+    poses = _collective_tensor(poses)
     out = [torch.zeros_like(poses) for _ in range(world)]
     dist.all_gather(out, poses)
     return torch.stack(out).cpu().numpy()
@@ -43,6 +50,7 @@ def gather_trajectories(poses, world):
 def max_over_ranks(value, device, world):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     if world > 1:
+        t = _collective_tensor(t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
