@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=32, help="frame pairs per step (<= 63)")
+    ap.add_argument("--pairs", type=int, default=63, help="frame pairs per step (<= 63)")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
