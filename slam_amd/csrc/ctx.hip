@@ -165,6 +165,11 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
     for (int k = 0; k < KTLVO_K_COUNT; k++)
         for (auto &pr : ctx->prof.pending[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : ctx->prof.pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < StageRing::N; i++) {
+        if (ctx->stage.h_buf[i]) (void)hipHostFree(ctx->stage.h_buf[i]);
+        if (ctx->stage.d_buf[i]) (void)hipFree(ctx->stage.d_buf[i]);
+        if (ctx->stage.done[i]) (void)hipEventDestroy(ctx->stage.done[i]);
+    }
     for (int i = 0; i < 4; i++) if (ctx->d_pts[i]) (void)hipFree(ctx->d_pts[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_err) (void)hipFree(ctx->d_err);

@@ -44,6 +44,16 @@ struct Profiler {
     long long launches[KTLVO_K_COUNT] = {0, 0, 0, 0, 0};
 };
 
+// Pinned host + device staging buffers for ktlvo_upload_image, used round-robin.
+struct StageRing {
+    static constexpr int N = 4;
+    uint8_t *h_buf[N] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *d_buf[N] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t done[N] = {nullptr, nullptr, nullptr, nullptr};
+    bool used[N] = {false, false, false, false};
+    int next = 0;
+};
+
 struct TrackerState; // tracker.hip
 
 } // namespace ktlvo
@@ -75,6 +85,7 @@ struct ktlvo_ctx {
     void *d_misc = nullptr; // corner / ransac work area
     size_t misc_bytes = 0;
 
+    ktlvo::StageRing stage;
     ktlvo::Profiler prof;
     ktlvo::TrackerState *tracker = nullptr;
 };

@@ -6,6 +6,8 @@
 // level's loader and the LK kernel read plain rows with no border arithmetic.
 #include "ctx.hpp"
 
+#include <cstring>
+
 namespace ktlvo {
 
 __device__ __forceinline__ int reflect101(int p, int n) {
@@ -14,14 +16,14 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-// Fills the frame of one level from its interior: thread per frame pixel.
-__global__ __launch_bounds__(256) void pad_border_u8(const SlotDesc *slots, SlotList list, int level) {
-    const LevelDesc L = slots[list.s[blockIdx.z]].lv[level];
+// Ingest: copies a w x h image (row stride `stride`) into level 0 of a slot and fills the
+// reflect-101 frame in the same pass: one thread per byte of the padded plane.
+__global__ __launch_bounds__(256) void ingest_pad_u8(const SlotDesc *slots, int slot, const uint8_t *src, int stride) {
+    const LevelDesc L = slots[slot].lv[0];
     const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) - PAD;
     const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PAD;
     if (x >= L.w + PAD || y >= L.h + PAD) return;
-    if (x >= 0 && x < L.w && y >= 0 && y < L.h) return;
-    L.origin[(ptrdiff_t)y * L.pitch + x] = L.origin[(ptrdiff_t)reflect101(y, L.h) * L.pitch + reflect101(x, L.w)];
+    L.origin[(ptrdiff_t)y * L.pitch + x] = src[(size_t)reflect101(y, L.h) * stride + reflect101(x, L.w)];
 }
 
 constexpr int TW = 64; // output tile
@@ -143,16 +145,9 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
     }
 }
 
-static int ingest(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride, hipMemcpyKind kind) {
-    if (!ctx || !img || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
-    if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w) return KTLVO_ERR_INVALID;
-    const LevelDesc &L = ctx->h_slots[slot].lv[0];
-    KTLVO_HIP(ctx, hipMemcpy2DAsync(L.origin, L.pitch, img, stride, w, h, kind, ctx->stream));
-    SlotList list;
-    list.n = 1;
-    list.s[0] = slot;
-    dim3 grid((w + 2 * PAD + 63) / 64, (h + 2 * PAD + 3) / 4, 1);
-    hipLaunchKernelGGL(pad_border_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, 0);
+static int launch_ingest(ktlvo_ctx *ctx, int slot, const uint8_t *d_src, int stride) {
+    dim3 grid((ctx->cfg.width + 2 * PAD + 63) / 64, (ctx->cfg.height + 2 * PAD + 3) / 4, 1);
+    hipLaunchKernelGGL(ingest_pad_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, d_src, stride);
     KTLVO_HIP(ctx, hipGetLastError());
     ctx->built[slot] = 0;
     ctx->deriv_ok[slot] = 0;
@@ -163,16 +158,42 @@ static int ingest(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, in
 
 using namespace ktlvo;
 
+// Host image -> pinned staging ring -> device staging -> padded plane.  A pageable 2-D copy with
+// differing pitches degenerates into one small transfer per row (measured 3.4 ms per KITTI frame);
+// staging through pinned memory makes it one contiguous DMA and lets the call return as soon as
+// the caller's buffer has been read.
 extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride) {
-    int rc = ingest(ctx, slot, img, w, h, stride, hipMemcpyHostToDevice);
+    if (!ctx || !img || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w) return KTLVO_ERR_INVALID;
+    const size_t bytes = (size_t)w * h;
+    StageRing &r = ctx->stage;
+    if (!r.h_buf[0]) {
+        for (int i = 0; i < StageRing::N; i++) {
+            KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_buf[i], bytes, hipHostMallocDefault));
+            KTLVO_HIP(ctx, hipMalloc((void **)&r.d_buf[i], bytes));
+            KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
+        }
+    }
+    const int k = r.next;
+    r.next = (r.next + 1) % StageRing::N;
+    if (r.used[k]) KTLVO_HIP(ctx, hipEventSynchronize(r.done[k])); // that buffer's previous DMA and ingest are over
+    if (stride == w) {
+        memcpy(r.h_buf[k], img, bytes);
+    } else {
+        for (int y = 0; y < h; y++) memcpy(r.h_buf[k] + (size_t)y * w, img + (size_t)y * stride, w);
+    }
+    KTLVO_HIP(ctx, hipMemcpyAsync(r.d_buf[k], r.h_buf[k], bytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_ingest(ctx, slot, r.d_buf[k], w);
     if (rc != KTLVO_OK) return rc;
-    // the source is pageable host memory the caller may reuse as soon as we return
-    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KTLVO_HIP(ctx, hipEventRecord(r.done[k], ctx->stream));
+    r.used[k] = true;
     return KTLVO_OK;
 }
 
 extern "C" int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride) {
-    return ingest(ctx, slot, d_img, w, h, stride, hipMemcpyDeviceToDevice);
+    if (!ctx || !d_img || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w) return KTLVO_ERR_INVALID;
+    return launch_ingest(ctx, slot, d_img, stride);
 }
 
 extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slots, int max_level, int win) {
