@@ -59,6 +59,9 @@ typedef struct {
     float ransac_reproj;           /* visualOdometry.cpp:126 (0.1f) */
     double ransac_conf;            /* visualOdometry.cpp:127 ((double)0.99f) */
     int max_hypotheses;            /* capacity of ktlvo_ransac_score */
+    int device_p3p;                /* 0: P3P hypotheses solved on the host (bit-parity with a host-side
+                                      solvePnPRansac); 1: solved by a HIP kernel, one thread per hypothesis
+                                      (same algorithm, device libm: poses agree to ~1e-12) */
 } ktlvo_config;
 
 /* cv::calcOpticalFlowPyrLK arguments as passed at featureTracking.cpp:205-209. */

@@ -57,6 +57,33 @@ __global__ __launch_bounds__(256) void ransac_score(const float *X3, const float
     if (tid == 0) counts[h] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
+// Minimal solver on the device: thread h takes index quadruple h, solves P3P in double
+// (p3p.hpp, the same code the host path runs), converts R -> rvec -> R as PnPRansacCallback's model
+// round trip does, and leaves R|t, rvec and a validity flag for the scoring launch.
+__global__ __launch_bounds__(64) void ransac_p3p(const float *X3, const float *x2, const int *idx, int H, double fx,
+                                                 double fy, double cx, double cy, double *Rt, double *rv,
+                                                 unsigned char *valid) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    const double K[4] = {fx, fy, cx, cy};
+    double Xs[12], us[8];
+    for (int i = 0; i < 4; i++) {
+        const int k = idx[4 * h + i];
+        Xs[3 * i] = X3[3 * k]; Xs[3 * i + 1] = X3[3 * k + 1]; Xs[3 * i + 2] = X3[3 * k + 2];
+        us[2 * i] = x2[2 * k]; us[2 * i + 1] = x2[2 * k + 1];
+    }
+    p3p::Pose P;
+    const bool ok = p3p::solve4(Xs, us, K, P);
+    valid[h] = ok ? 1 : 0;
+    double r[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (ok) {
+        p3p::rodrigues_m2v(P.R, r);
+        p3p::rodrigues_v2m(r, R);
+    }
+    for (int i = 0; i < 9; i++) Rt[12 * (size_t)h + i] = R[i];
+    for (int i = 0; i < 3; i++) { Rt[12 * (size_t)h + 9 + i] = ok ? P.t[i] : 0.0; rv[3 * (size_t)h + i] = r[i]; }
+}
+
 struct CvRng { // cv::RNG (multiply-with-carry)
     uint64_t state;
     explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
@@ -80,21 +107,23 @@ static int update_num_iters(double p, double ep, int modelPoints, int maxIters) 
 
 struct ScoreBuffers {
     float *d_X3, *d_x2;
-    double *d_Rt;
+    double *d_Rt, *d_rv;
     unsigned char *d_valid, *d_mask;
-    int *d_counts;
+    int *d_counts, *d_idx;
 };
 
 static int carve_score(ktlvo_ctx *ctx, int n, int H, ScoreBuffers &b) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_X = 0, o_x = o_X + up((size_t)n * 12), o_Rt = o_x + up((size_t)n * 8);
     const size_t o_valid = o_Rt + up((size_t)H * 96), o_mask = o_valid + up(H), o_cnt = o_mask + up(n);
-    const size_t total = o_cnt + up((size_t)H * 4);
+    const size_t o_rv = o_cnt + up((size_t)H * 4), o_idx = o_rv + up((size_t)H * 24);
+    const size_t total = o_idx + up((size_t)H * 16);
     int rc = ensure_misc(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *p = (char *)ctx->d_misc;
     b.d_X3 = (float *)(p + o_X); b.d_x2 = (float *)(p + o_x); b.d_Rt = (double *)(p + o_Rt);
     b.d_valid = (unsigned char *)(p + o_valid); b.d_mask = (unsigned char *)(p + o_mask); b.d_counts = (int *)(p + o_cnt);
+    b.d_rv = (double *)(p + o_rv); b.d_idx = (int *)(p + o_idx);
     return KTLVO_OK;
 }
 
@@ -168,35 +197,46 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
         }
     }
     // 2. minimal solver per hypothesis; the model is kept as (rvec, tvec) and R is rebuilt from
-    //    rvec for scoring, as PnPRansacCallback does
+    //    rvec for scoring, as PnPRansacCallback does.  3. one launch scores every hypothesis.
     std::vector<double> Rt((size_t)12 * H, 0.0), rv((size_t)3 * H, 0.0);
     std::vector<unsigned char> valid(H, 0);
-    for (int it = 0; it < H; it++) {
-        double Xs[12], us[8];
-        for (int i = 0; i < 4; i++) {
-            const int k = idx[4 * (size_t)it + i];
-            Xs[3 * i] = X3[3 * k]; Xs[3 * i + 1] = X3[3 * k + 1]; Xs[3 * i + 2] = X3[3 * k + 2];
-            us[2 * i] = x2[2 * k]; us[2 * i + 1] = x2[2 * k + 1];
-        }
-        p3p::Pose P;
-        if (!p3p::solve4(Xs, us, K, P)) continue;
-        valid[it] = 1;
-        p3p::rodrigues_m2v(P.R, &rv[3 * (size_t)it]);
-        p3p::rodrigues_v2m(&rv[3 * (size_t)it], &Rt[12 * (size_t)it]);
-        memcpy(&Rt[12 * (size_t)it + 9], P.t, 3 * sizeof(double));
-    }
-    // 3. one launch scores every hypothesis
+    std::vector<int> counts(H);
     ScoreBuffers b;
     int rc = carve_score(ctx, n, H, b);
     if (rc != KTLVO_OK) return rc;
     KTLVO_HIP(ctx, hipMemcpyAsync(b.d_X3, X3, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     KTLVO_HIP(ctx, hipMemcpyAsync(b.d_x2, x2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(b.d_Rt, Rt.data(), (size_t)H * 96, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(b.d_valid, valid.data(), H, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->cfg.device_p3p) {
+        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_idx, idx.data(), (size_t)H * 16, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ransac_p3p, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, b.d_X3, b.d_x2, b.d_idx, H, K[0],
+                           K[1], K[2], K[3], b.d_Rt, b.d_rv, b.d_valid);
+        KTLVO_HIP(ctx, hipGetLastError());
+    } else {
+        for (int it = 0; it < H; it++) {
+            double Xs[12], us[8];
+            for (int i = 0; i < 4; i++) {
+                const int k = idx[4 * (size_t)it + i];
+                Xs[3 * i] = X3[3 * k]; Xs[3 * i + 1] = X3[3 * k + 1]; Xs[3 * i + 2] = X3[3 * k + 2];
+                us[2 * i] = x2[2 * k]; us[2 * i + 1] = x2[2 * k + 1];
+            }
+            p3p::Pose P;
+            if (!p3p::solve4(Xs, us, K, P)) continue;
+            valid[it] = 1;
+            p3p::rodrigues_m2v(P.R, &rv[3 * (size_t)it]);
+            p3p::rodrigues_v2m(&rv[3 * (size_t)it], &Rt[12 * (size_t)it]);
+            memcpy(&Rt[12 * (size_t)it + 9], P.t, 3 * sizeof(double));
+        }
+        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_Rt, Rt.data(), (size_t)H * 96, hipMemcpyHostToDevice, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_valid, valid.data(), H, hipMemcpyHostToDevice, ctx->stream));
+    }
     rc = launch_score(ctx, b, n, H, b.d_valid, K, thr_sq, -1, false);
     if (rc != KTLVO_OK) return rc;
-    std::vector<int> counts(H);
     KTLVO_HIP(ctx, hipMemcpyAsync(counts.data(), b.d_counts, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->cfg.device_p3p) {
+        KTLVO_HIP(ctx, hipMemcpyAsync(valid.data(), b.d_valid, H, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(Rt.data(), b.d_Rt, (size_t)H * 96, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(rv.data(), b.d_rv, (size_t)H * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // 4. replay of the sequential acceptance rule
     int niters = H, best = -1, maxGood = 0;

@@ -44,6 +44,7 @@ class Config(C.Structure):
         ("anms_keep", C.c_int), ("keyframe_min_tracked", C.c_int),
         ("ransac_iters", C.c_int), ("ransac_reproj", C.c_float), ("ransac_conf", C.c_double),
         ("max_hypotheses", C.c_int),
+        ("device_p3p", C.c_int),
     ]
 
 

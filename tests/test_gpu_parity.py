@@ -404,3 +404,27 @@ def test_full_size_frames(make_ctx, oracle, klib, size, ncorners, min_dist):
     r, rs, _ = ctx.pyrlk(1, 0, go)                                   # forward-backward
     ok = (gs == 1) & (rs == 1)
     assert np.median(np.abs(r - xy)[ok]) < 0.02
+
+
+def test_device_p3p_matches_host_p3p(make_ctx, oracle):
+    """Hypothesis generation on the GPU (one thread per P3P) against the host solver: same
+    algorithm, device libm, so poses agree to rounding and the selected model is the same."""
+    g = np.load(os.path.join(GOLD, "ransac_400.npz"))
+    host = make_ctx().solve_pnp_ransac(g["X3"], g["x2"])
+    dev = make_ctx(device_p3p=1).solve_pnp_ransac(g["X3"], g["x2"])
+    assert dev["ok"] and abs(dev["n_inliers"] - host["n_inliers"]) <= 1
+    assert np.abs(dev["rvec"] - host["rvec"]).max() < 1e-9 and np.abs(dev["tvec"] - host["tvec"]).max() < 1e-9
+    assert (dev["mask"] != host["mask"]).sum() <= 1
+    # max-size batch: 1024 hypotheses
+    rng = np.random.default_rng(5)
+    X = np.stack([rng.uniform(-8, 8, 3000), rng.uniform(-2, 2, 3000), rng.uniform(4, 38, 3000)], 1).astype(np.float32)
+    R = oracle.rodrigues_v2m(np.array([0.01, -0.02, 0.005]))
+    Xc = X.astype(np.float64) @ R.T + np.array([0.05, 0.0, -0.7])
+    K = np.array([707.0912, 707.0912, 601.8873, 183.1104])
+    uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
+    uv = (uv + rng.normal(size=uv.shape) * 0.03).astype(np.float32)
+    a = make_ctx().solve_pnp_ransac(X, uv, max_iters=1024)
+    b = make_ctx(device_p3p=1).solve_pnp_ransac(X, uv, max_iters=1024)
+    assert a["ok"] and b["ok"] and abs(a["n_inliers"] - b["n_inliers"]) <= 2
+    assert np.abs(a["rvec"] - b["rvec"]).max() < 1e-8 and np.abs(a["tvec"] - b["tvec"]).max() < 1e-8
+    assert np.abs(b["rvec"] - np.array([0.01, -0.02, 0.005])).max() < 2e-3
