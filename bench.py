@@ -303,10 +303,7 @@ def main():
         for _ in range(levels):
             lv_bytes += w_ * h_
             w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
-        # the grid deals pairs to the 8 XCDs, so it is rounded up to a multiple of 8 pairs; the
-        # surplus waves exit at once but are counted by SQ_WAVES
-        waves_per_launch = 8 * ((args.pairs + 7) // 8) * (feats_per_launch // args.pairs)
-        traffic, traffic_src = measured_traffic("pyrlk_track_w21", waves_per_launch)
+        traffic, traffic_src = measured_traffic("pyrlk_track_w21", feats_per_launch)
         out = {
             "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
             "value": value,

@@ -32,6 +32,7 @@ struct LkArgs {
     int max_level;
     int max_count;
     double eps_sq;
+    float eps_lo, eps_hi; // float step^2 at or below eps_lo passes, at or above eps_hi fails, without doubles
     double min_eig_thr;
     const int *d_n; // optional: actual point count lives in device memory (<= n_per_pair)
     PairList pairs;
@@ -65,9 +66,37 @@ __device__ __forceinline__ float wave_sum(float v) {
         "s_nop 1\n\t"
         "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc\n\t" // rows 2, 3 += lane 31
         "s_nop 1\n\t"
-        "v_readlane_b32 %0, %1, 63"
+        "v_readlane_b32 %0, %1, 63\n\t"
+        "s_nop 1" // before a VALU read of the SGPR
         : "=s"(total), "+v"(v));
     return __int_as_float(total);
+}
+
+// Two sums at once: v_permlane32_swap puts a's two halves side by side in one register pair and b's
+// in the other, so one add folds both to 32 lanes and the remaining tree runs on a single register
+// (lanes 0-31 carry a, lanes 32-63 carry b).
+struct Sum2 {
+    float a, b;
+};
+__device__ __forceinline__ Sum2 wave_sum2(float a, float b) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    v = dpp_add<0xB1, 0xF>(v);
+    v = dpp_add<0x4E, 0xF>(v);
+    v = dpp_add<0x141, 0xF>(v);
+    v = dpp_add<0x140, 0xF>(v);
+    int ta, tb;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa\n\t" // rows 1, 3 += lane 15 of rows 0, 2
+        "s_nop 1\n\t"
+        "v_readlane_b32 %0, %2, 31\n\t"
+        "v_readlane_b32 %1, %2, 63\n\t"
+        "s_nop 1" // before a VALU read of the SGPRs
+        : "=&s"(ta), "=&s"(tb), "+v"(v));
+    Sum2 r;
+    r.a = __int_as_float(ta);
+    r.b = __int_as_float(tb);
+    return r;
 }
 
 // a * b + c on 24-bit signed factors (every factor here is below 2^15 in magnitude); written as
@@ -153,18 +182,39 @@ constexpr int WIN = 21;
 constexpr int RUN = 7;
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Lane 0's (x, y) as scalar registers.  Unlike the builtin this is opaque to the compiler, so the
+// values and everything derived from them (bounds tests, row offset) stay on the scalar unit instead
+// of being recomputed per lane.  gfx950 wait states the compiler cannot insert around asm: one after
+// the VALU write of a VGPR that v_readfirstlane reads, two before a VALU read of the SGPR it wrote.
+__device__ __forceinline__ void scalar_xy(int vx, int vy, int &sx, int &sy) {
+    asm("s_nop 0\n\t"
+        "v_readfirstlane_b32 %0, %2\n\t"
+        "v_readfirstlane_b32 %1, %3\n\t"
+        "s_nop 1"
+        : "=&s"(sx), "=&s"(sy)
+        : "v"(vx), "v"(vy));
+}
 
 __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = uniform((int)(threadIdx.x >> 6));
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each with its
-    // own 4 MiB L2.  All workgroups of a frame pair are therefore given block ids of one residue
-    // class mod 8, so a pair's two pyramids are fetched into one L2 instead of eight.  This is a
-    // locality hint only; any placement gives the same results.
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int pair = xcd + 8 * (q / a.blocks_per_pair);
-    if (pair >= a.n_pairs) return;
-    const int f = (q % a.blocks_per_pair) * 4 + wave;
+    // own 4 MiB L2.  Pairs are taken in groups of 8: all workgroups of a group's pair i get block ids
+    // of residue class i mod 8, so a pair's two pyramids are fetched into one L2 instead of eight.
+    // The pairs left over after the last full group are spread over all XCDs, so none runs dry
+    // early.  This is a locality hint only; any placement gives the same results.
+    const int grouped = (a.n_pairs >> 3) * 8 * a.blocks_per_pair; // blocks of the full groups
+    int pair, blk;
+    if ((int)blockIdx.x < grouped) {
+        const int q = blockIdx.x >> 3;
+        pair = (blockIdx.x & 7) + 8 * (q / a.blocks_per_pair);
+        blk = q % a.blocks_per_pair;
+    } else {
+        const int q = blockIdx.x - grouped;
+        pair = (a.n_pairs & ~7) + q / a.blocks_per_pair;
+        blk = q % a.blocks_per_pair;
+    }
+    const int f = blk * 4 + wave;
     const int n = a.d_n ? min(*a.d_n, a.n_per_pair) : a.n_per_pair;
     if (f >= n) return;
     const SlotDesc &SP = a.slots[a.pairs.prev[pair]];
@@ -260,15 +310,26 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         // ---- Gauss-Newton iterations -----------------------------------------------------------
         float nx = ox - halfWin, ny = oy - halfWin;
         float pdx = 0.f, pdy = 0.f;
+        // The rows fetched for one step serve the following steps as long as the window's integer
+        // corner stays put, which is the rule once the first step or two of a level are done: only
+        // the weights change then, and the step needs no memory access at all.
+        int have_x = INT_MIN, have_y = INT_MIN;
+        Run8 t = {0u, 0u}, b = {0u, 0u};
         for (int j = 0; j < a.max_count; j++) {
-            const int inx = uniform((int)floorf(nx)), iny = uniform((int)floorf(ny));
+            const float flx = floorf(nx), fly = floorf(ny);
+            int inx, iny;
+            scalar_xy((int)flx, (int)fly, inx, iny);
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 if (level == 0) status = 0;
                 break;
             }
-            w = bilinear_weights(nx - (float)inx, ny - (float)iny);
-            const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
-            const Run8 t = load_run8(Jbase, e0), b = load_run8(Jbase, e0 + pitch);
+            w = bilinear_weights(nx - flx, ny - fly);
+            if (inx != have_x || iny != have_y) {
+                const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
+                t = load_run8(Jbase, e0);
+                b = load_run8(Jbase, e0 + pitch);
+                have_x = inx; have_y = iny;
+            }
             int diff[RUN];
             sample_run(t, b, w, Ineg, diff);
             int b1 = 0, b2 = 0;
@@ -277,13 +338,17 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 b1 = mad24(diff[i], ixv[i], b1);
                 b2 = mad24(diff[i], iyv[i], b2);
             }
-            const float fb1 = wave_sum((float)b1) * FLT_SCALE;
-            const float fb2 = wave_sum((float)b2) * FLT_SCALE;
+            const Sum2 bs = wave_sum2((float)b1, (float)b2);
+            const float fb1 = bs.a * FLT_SCALE, fb2 = bs.b * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nx += dx; ny += dy;
             ox = nx + halfWin; oy = ny + halfWin;
-            if ((double)dx * dx + (double)dy * dy <= a.eps_sq) break;
+            // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
+            // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
+            const float step_sq = dx * dx + dy * dy;
+            if (step_sq <= a.eps_lo) break;
+            if (step_sq < a.eps_hi && (double)dx * dx + (double)dy * dy <= a.eps_sq) break;
             // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
             // so "<= 0.01f" is the same predicate without leaving single precision
             if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
@@ -301,8 +366,11 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 status = 0;
             } else {
                 w = bilinear_weights(fx - (float)inx, fy - (float)iny);
-                const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
-                const Run8 t = load_run8(Jbase, e0), b = load_run8(Jbase, e0 + pitch);
+                if (inx != have_x || iny != have_y) {
+                    const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
+                    t = load_run8(Jbase, e0);
+                    b = load_run8(Jbase, e0 + pitch);
+                }
                 int diff[RUN];
                 sample_run(t, b, w, Ineg, diff);
                 int e = 0;
@@ -354,14 +422,20 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     a.max_count = mc < 0 ? 0 : mc > 100 ? 100 : mc;
     double eps = p->epsilon < 0 ? 0 : p->epsilon > 10 ? 10 : p->epsilon;
     a.eps_sq = eps * eps;
+    if (a.eps_sq >= 1e-30) {
+        a.eps_lo = (float)(a.eps_sq * (1.0 - 1e-6));
+        a.eps_hi = (float)(a.eps_sq * (1.0 + 1e-6));
+    } else { // float squares may underflow here: always decide in double
+        a.eps_lo = -1.f;
+        a.eps_hi = __builtin_inff();
+    }
     a.min_eig_thr = p->min_eig_thr;
     a.d_n = d_n;
     a.pairs = pairs;
     for (int i = 0; i < n_pairs; i++) { a.prev_off[i] = prev_off[i]; a.next_off[i] = next_off[i]; }
     a.n_pairs = n_pairs;
     a.blocks_per_pair = (n_per_pair + 3) / 4;
-    // 8 residue classes x ceil(n_pairs / 8) pairs each x blocks per pair
-    dim3 grid((unsigned)(8 * ((n_pairs + 7) / 8) * a.blocks_per_pair));
+    dim3 grid((unsigned)(n_pairs * a.blocks_per_pair));
     ProfScope ps(ctx, KTLVO_K_PYRLK);
     hipLaunchKernelGGL(pyrlk_track_w21, grid, dim3(256), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
