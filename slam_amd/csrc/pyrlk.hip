@@ -161,21 +161,39 @@ __device__ __forceinline__ uint32_t col_pair(const Run8 &t, const Run8 &b) {
     constexpr uint32_t sel = 0x0c000c00u | (uint32_t)(K & 3) | ((uint32_t)((K & 3) + 4) << 16);
     return K < 4 ? __builtin_amdgcn_perm(b.lo, t.lo, sel) : __builtin_amdgcn_perm(b.hi, t.hi, sel);
 }
+// The eight vertical pixel pairs of a lane's two fetched rows.
+struct Cols {
+    uint32_t c[8];
+};
+__device__ __forceinline__ Cols col_pairs(const Run8 &t, const Run8 &b) {
+    Cols k;
+    k.c[0] = col_pair<0>(t, b); k.c[1] = col_pair<1>(t, b); k.c[2] = col_pair<2>(t, b); k.c[3] = col_pair<3>(t, b);
+    k.c[4] = col_pair<4>(t, b); k.c[5] = col_pair<5>(t, b); k.c[6] = col_pair<6>(t, b); k.c[7] = col_pair<7>(t, b);
+    return k;
+}
 // The seven fixed-point bilinear samples (scaled by 32) of a lane's run: v[i] = CV_DESCALE(sum, 9)
 // + (acc0[i] - 256) / 512.  With acc0 = 256 this is the sample itself; with acc0 = 256 - 512 * I it is
 // sample - I at no extra cost (the subtrahend is a multiple of 2^9, so it commutes with the shift).
 // Signed dots: the remainder weight w11 can be -1 when the three rounded weights sum to 16385.
-__device__ __forceinline__ void sample_run(const Run8 &t, const Run8 &b, const Weights &w, const int (&acc0)[7],
-                                           int (&v)[7]) {
-    const uint32_t c0 = col_pair<0>(t, b), c1 = col_pair<1>(t, b), c2 = col_pair<2>(t, b), c3 = col_pair<3>(t, b);
-    const uint32_t c4 = col_pair<4>(t, b), c5 = col_pair<5>(t, b), c6 = col_pair<6>(t, b), c7 = col_pair<7>(t, b);
-    v[0] = sdot2(c1, w.wr, sdot2(c0, w.wl, acc0[0])) >> 9;
-    v[1] = sdot2(c2, w.wr, sdot2(c1, w.wl, acc0[1])) >> 9;
-    v[2] = sdot2(c3, w.wr, sdot2(c2, w.wl, acc0[2])) >> 9;
-    v[3] = sdot2(c4, w.wr, sdot2(c3, w.wl, acc0[3])) >> 9;
-    v[4] = sdot2(c5, w.wr, sdot2(c4, w.wl, acc0[4])) >> 9;
-    v[5] = sdot2(c6, w.wr, sdot2(c5, w.wl, acc0[5])) >> 9;
-    v[6] = sdot2(c7, w.wr, sdot2(c6, w.wl, acc0[6])) >> 9;
+__device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, const int (&acc0)[7], int (&v)[7]) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = sdot2(k.c[i + 1], w.wr, sdot2(k.c[i], w.wl, acc0[i])) >> 9;
+}
+// int16 pairs (v0, v1), (v2, v3), (v4, v5), (v6, 0) of seven values that fit 16 bits
+struct Packed7 {
+    uint32_t p[4];
+};
+__device__ __forceinline__ Packed7 pack7(const int (&v)[7]) {
+    Packed7 r;
+    r.p[0] = __builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u);
+    r.p[1] = __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u);
+    r.p[2] = __builtin_amdgcn_perm((uint32_t)v[5], (uint32_t)v[4], 0x05040100u);
+    r.p[3] = (uint32_t)v[6] & 0xFFFFu;
+    return r;
+}
+// sum of x[i] * y[i] over the seven values, exact in int32
+__device__ __forceinline__ int dot7(const Packed7 &x, const Packed7 &y) {
+    return sdot2(x.p[3], y.p[3], sdot2(x.p[2], y.p[2], sdot2(x.p[1], y.p[1], sdot2(x.p[0], y.p[0], 0))));
 }
 
 constexpr int WIN = 21;
@@ -195,7 +213,7 @@ __device__ __forceinline__ void scalar_xy(int vx, int vy, int &sx, int &sy) {
         : "v"(vx), "v"(vy));
 }
 
-__global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void pyrlk_track_w21(LkArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = uniform((int)(threadIdx.x >> 6));
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each with its
@@ -258,7 +276,8 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         Weights w = bilinear_weights(px - (float)ipx, py - (float)ipy);
 
         // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
-        int Ineg[RUN], ixv[RUN], iyv[RUN]; // Ineg = 256 - 512 * I: accumulator start of the mismatch samples
+        int Ineg[RUN];     // 256 - 512 * I: accumulator start of the mismatch samples
+        Packed7 ixp, iyp;  // the template's derivatives as int16 pairs
         {
             const uint32_t e0 = lane_off + (uint32_t)(ipy * pitch + ipx);
             const Run8 t = load_run8(Ibase, e0), b = load_run8(Ibase, e0 + pitch);
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
             {
                 const int round9[RUN] = {256, 256, 256, 256, 256, 256, 256};
                 int Iv[RUN];
-                sample_run(t, b, w, round9, Iv);
+                sample_run(col_pairs(t, b), w, round9, Iv);
 #pragma unroll
                 for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
             }
@@ -282,19 +301,16 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 cxp[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x05040100u);
                 cyp[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
             }
+            int ixv[RUN], iyv[RUN];
 #pragma unroll
             for (int i = 0; i < RUN; i++) {
                 ixv[i] = sdot2(cxp[i + 1], w.wr, sdot2(cxp[i], w.wl, 1 << 13)) >> 14;
                 iyv[i] = sdot2(cyp[i + 1], w.wr, sdot2(cyp[i], w.wl, 1 << 13)) >> 14;
             }
+            ixp = pack7(ixv);
+            iyp = pack7(iyv);
         }
-        int s11 = 0, s12 = 0, s22 = 0;
-#pragma unroll
-        for (int i = 0; i < RUN; i++) {
-            s11 = mad24(ixv[i], ixv[i], s11);
-            s12 = mad24(ixv[i], iyv[i], s12);
-            s22 = mad24(iyv[i], iyv[i], s22);
-        }
+        const int s11 = dot7(ixp, ixp), s12 = dot7(ixp, iyp), s22 = dot7(iyp, iyp);
         const float A11 = wave_sum((float)s11) * FLT_SCALE;
         const float A12 = wave_sum((float)s12) * FLT_SCALE;
         const float A22 = wave_sum((float)s22) * FLT_SCALE;
@@ -312,50 +328,64 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
         float pdx = 0.f, pdy = 0.f;
         // The rows fetched for one step serve the following steps as long as the window's integer
         // corner stays put, which is the rule once the first step or two of a level are done: only
-        // the weights change then, and the step needs no memory access at all.
+        // the weights change then, and the step needs no memory access at all.  Hence two loops: the
+        // outer one fetches for a new corner, the inner one steps with the column pairs held fixed.
         int have_x = INT_MIN, have_y = INT_MIN;
-        Run8 t = {0u, 0u}, b = {0u, 0u};
-        for (int j = 0; j < a.max_count; j++) {
-            const float flx = floorf(nx), fly = floorf(ny);
-            int inx, iny;
-            scalar_xy((int)flx, (int)fly, inx, iny);
+        Cols cols = {};
+        int j = 0;
+        bool more = a.max_count > 0;
+        float flx = floorf(nx), fly = floorf(ny);
+        int inx, iny;
+        scalar_xy((int)flx, (int)fly, inx, iny);
+        while (more) {
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 if (level == 0) status = 0;
                 break;
             }
-            w = bilinear_weights(nx - flx, ny - fly);
-            if (inx != have_x || iny != have_y) {
+            {
                 const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
-                t = load_run8(Jbase, e0);
-                b = load_run8(Jbase, e0 + pitch);
+                cols = col_pairs(load_run8(Jbase, e0), load_run8(Jbase, e0 + pitch));
                 have_x = inx; have_y = iny;
             }
-            int diff[RUN];
-            sample_run(t, b, w, Ineg, diff);
-            int b1 = 0, b2 = 0;
-#pragma unroll
-            for (int i = 0; i < RUN; i++) {
-                b1 = mad24(diff[i], ixv[i], b1);
-                b2 = mad24(diff[i], iyv[i], b2);
+            for (;;) {
+                w = bilinear_weights(nx - flx, ny - fly);
+                int diff[RUN];
+                sample_run(cols, w, Ineg, diff);
+                const Packed7 dp = pack7(diff); // |diff| <= 255 * 32
+                const int b1 = dot7(dp, ixp), b2 = dot7(dp, iyp);
+                const Sum2 bs = wave_sum2((float)b1, (float)b2);
+                const float fb1 = bs.a * FLT_SCALE, fb2 = bs.b * FLT_SCALE;
+                const float dx = (A12 * fb2 - A22 * fb1) * D;
+                const float dy = (A12 * fb1 - A11 * fb2) * D;
+                nx += dx; ny += dy;
+                ox = nx + halfWin; oy = ny + halfWin;
+                // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
+                // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
+                const float step_sq = dx * dx + dy * dy;
+                if (step_sq <= a.eps_lo || (step_sq < a.eps_hi && (double)dx * dx + (double)dy * dy <= a.eps_sq)) {
+                    more = false;
+                    break;
+                }
+                // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
+                // so "<= 0.01f" is the same predicate without leaving single precision
+                if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+                    ox -= dx * 0.5f; oy -= dy * 0.5f;
+                    more = false;
+                    break;
+                }
+                if (++j >= a.max_count) {
+                    more = false;
+                    break;
+                }
+                pdx = dx; pdy = dy;
+                flx = floorf(nx); fly = floorf(ny);
+                int kx, ky;
+                scalar_xy((int)flx, (int)fly, kx, ky);
+                if (kx != inx || ky != iny) { // new corner: bounds test and fetch in the outer loop
+                    inx = kx; iny = ky;
+                    break;
+                }
             }
-            const Sum2 bs = wave_sum2((float)b1, (float)b2);
-            const float fb1 = bs.a * FLT_SCALE, fb2 = bs.b * FLT_SCALE;
-            const float dx = (A12 * fb2 - A22 * fb1) * D;
-            const float dy = (A12 * fb1 - A11 * fb2) * D;
-            nx += dx; ny += dy;
-            ox = nx + halfWin; oy = ny + halfWin;
-            // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
-            // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
-            const float step_sq = dx * dx + dy * dy;
-            if (step_sq <= a.eps_lo) break;
-            if (step_sq < a.eps_hi && (double)dx * dx + (double)dy * dy <= a.eps_sq) break;
-            // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
-            // so "<= 0.01f" is the same predicate without leaving single precision
-            if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-                ox -= dx * 0.5f; oy -= dy * 0.5f;
-                break;
-            }
-            pdx = dx; pdy = dy;
         }
 
         // ---- final error (level 0 only) ------------------------------------------------------
@@ -368,11 +398,10 @@ __global__ __launch_bounds__(256) void pyrlk_track_w21(LkArgs a) {
                 w = bilinear_weights(fx - (float)inx, fy - (float)iny);
                 if (inx != have_x || iny != have_y) {
                     const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
-                    t = load_run8(Jbase, e0);
-                    b = load_run8(Jbase, e0 + pitch);
+                    cols = col_pairs(load_run8(Jbase, e0), load_run8(Jbase, e0 + pitch));
                 }
                 int diff[RUN];
-                sample_run(t, b, w, Ineg, diff);
+                sample_run(cols, w, Ineg, diff);
                 int e = 0;
 #pragma unroll
                 for (int i = 0; i < RUN; i++) e += diff[i] < 0 ? -diff[i] : diff[i];
