@@ -99,24 +99,13 @@ __device__ __forceinline__ Sum2 wave_sum2(float a, float b) {
     return r;
 }
 
-// a * b + c on 24-bit signed factors (every factor here is below 2^15 in magnitude); written as
-// asm because clang has no builtin for it and falls back to the quarter-rate 32-bit multiply.
-__device__ __forceinline__ int mad24(int a, int b, int c) {
-    int d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-// a.lo * b.lo + a.hi * b.hi + c on int16 pairs.  Written as asm to get the three-address VOP3P
-// form: the builtin is selected as v_dot2c (dst == accumulator), which costs a v_mov whenever the
-// accumulator input has to survive (it always does here: it is the template).
-__device__ __forceinline__ int sdot2(uint32_t a, uint32_t b, int c) {
-    int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
-}
+// The int16-pair dot products (v_dot2_i32_i16: a.lo * b.lo + a.hi * b.hi + c) are written as asm
+// blocks, because the builtin is selected as v_dot2c (dst == accumulator) and then costs a v_mov per
+// use whenever the accumulator input has to survive, as the template does here.  gfx950 needs three
+// wait states between a dot instruction's write and any other kind of VALU instruction touching that
+// register (a following dot may take it as its accumulator at once), and the compiler does not see
+// into asm: so every block keeps its dots together and ends with s_nop 2, after which its results
+// are ordinary registers.
 
 // Bilinear weights as OpenCV forms them: cvRound of float products scaled by 2^14, the fourth
 // as the remainder.  They are packed per COLUMN: wl = (w00 | w10 << 16) weighs the left pixel of
@@ -176,8 +165,27 @@ __device__ __forceinline__ Cols col_pairs(const Run8 &t, const Run8 &b) {
 // sample - I at no extra cost (the subtrahend is a multiple of 2^9, so it commutes with the shift).
 // Signed dots: the remainder weight w11 can be -1 when the three rounded weights sum to 16385.
 __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, const int (&acc0)[7], int (&v)[7]) {
-#pragma unroll
-    for (int i = 0; i < 7; i++) v[i] = sdot2(k.c[i + 1], w.wr, sdot2(k.c[i], w.wl, acc0[i])) >> 9;
+    int d0, d1, d2, d3, d4, d5, d6;
+    asm("v_dot2_i32_i16 %0, %7, %15, %17\n\t"
+        "v_dot2_i32_i16 %1, %8, %15, %18\n\t"
+        "v_dot2_i32_i16 %2, %9, %15, %19\n\t"
+        "v_dot2_i32_i16 %3, %10, %15, %20\n\t"
+        "v_dot2_i32_i16 %4, %11, %15, %21\n\t"
+        "v_dot2_i32_i16 %5, %12, %15, %22\n\t"
+        "v_dot2_i32_i16 %6, %13, %15, %23\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %16, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %16, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %16, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %16, %5\n\t"
+        "v_dot2_i32_i16 %6, %14, %16, %6\n\t"
+        "s_nop 2"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6)
+        : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
+          "v"(w.wl), "v"(w.wr), "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]),
+          "v"(acc0[6]));
+    v[0] = d0 >> 9; v[1] = d1 >> 9; v[2] = d2 >> 9; v[3] = d3 >> 9; v[4] = d4 >> 9; v[5] = d5 >> 9; v[6] = d6 >> 9;
 }
 // int16 pairs (v0, v1), (v2, v3), (v4, v5), (v6, 0) of seven values that fit 16 bits
 struct Packed7 {
@@ -191,9 +199,36 @@ __device__ __forceinline__ Packed7 pack7(const int (&v)[7]) {
     r.p[3] = (uint32_t)v[6] & 0xFFFFu;
     return r;
 }
-// sum of x[i] * y[i] over the seven values, exact in int32
+// (sum of x[i] * y[i], sum of x[i] * z[i]) over the seven values, exact in int32
+struct Dot2 {
+    int xy, xz;
+};
+__device__ __forceinline__ Dot2 dot7x2(const Packed7 &x, const Packed7 &y, const Packed7 &z) {
+    Dot2 r;
+    asm("v_dot2_i32_i16 %0, %2, %6, 0\n\t"
+        "v_dot2_i32_i16 %1, %2, %10, 0\n\t"
+        "v_dot2_i32_i16 %0, %3, %7, %0\n\t"
+        "v_dot2_i32_i16 %1, %3, %11, %1\n\t"
+        "v_dot2_i32_i16 %0, %4, %8, %0\n\t"
+        "v_dot2_i32_i16 %1, %4, %12, %1\n\t"
+        "v_dot2_i32_i16 %0, %5, %9, %0\n\t"
+        "v_dot2_i32_i16 %1, %5, %13, %1\n\t"
+        "s_nop 2"
+        : "=&v"(r.xy), "=&v"(r.xz)
+        : "v"(x.p[0]), "v"(x.p[1]), "v"(x.p[2]), "v"(x.p[3]), "v"(y.p[0]), "v"(y.p[1]), "v"(y.p[2]), "v"(y.p[3]),
+          "v"(z.p[0]), "v"(z.p[1]), "v"(z.p[2]), "v"(z.p[3]));
+    return r;
+}
 __device__ __forceinline__ int dot7(const Packed7 &x, const Packed7 &y) {
-    return sdot2(x.p[3], y.p[3], sdot2(x.p[2], y.p[2], sdot2(x.p[1], y.p[1], sdot2(x.p[0], y.p[0], 0))));
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %5, 0\n\t"
+        "v_dot2_i32_i16 %0, %2, %6, %0\n\t"
+        "v_dot2_i32_i16 %0, %3, %7, %0\n\t"
+        "v_dot2_i32_i16 %0, %4, %8, %0\n\t"
+        "s_nop 2"
+        : "=&v"(r)
+        : "v"(x.p[0]), "v"(x.p[1]), "v"(x.p[2]), "v"(x.p[3]), "v"(y.p[0]), "v"(y.p[1]), "v"(y.p[2]), "v"(y.p[3]));
+    return r;
 }
 
 constexpr int WIN = 21;
@@ -295,22 +330,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
             }
             // column pairs (top, bottom) of dx and of dy; each serves two neighbouring samples
-            uint32_t cxp[RUN + 1], cyp[RUN + 1];
+            Cols cxp, cyp;
 #pragma unroll
             for (int k = 0; k <= RUN; k++) {
-                cxp[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x05040100u);
-                cyp[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
+                cxp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x05040100u);
+                cyp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
             }
+            // CV_DESCALE(sum, 14) = ((sum + 2^13) >> 9) >> 5, as the low nine bits only get dropped
+            const int round14[RUN] = {1 << 13, 1 << 13, 1 << 13, 1 << 13, 1 << 13, 1 << 13, 1 << 13};
             int ixv[RUN], iyv[RUN];
+            sample_run(cxp, w, round14, ixv);
+            sample_run(cyp, w, round14, iyv);
 #pragma unroll
-            for (int i = 0; i < RUN; i++) {
-                ixv[i] = sdot2(cxp[i + 1], w.wr, sdot2(cxp[i], w.wl, 1 << 13)) >> 14;
-                iyv[i] = sdot2(cyp[i + 1], w.wr, sdot2(cyp[i], w.wl, 1 << 13)) >> 14;
-            }
+            for (int i = 0; i < RUN; i++) { ixv[i] >>= 5; iyv[i] >>= 5; }
             ixp = pack7(ixv);
             iyp = pack7(iyv);
         }
-        const int s11 = dot7(ixp, ixp), s12 = dot7(ixp, iyp), s22 = dot7(iyp, iyp);
+        const Dot2 sxx = dot7x2(ixp, ixp, iyp);
+        const int s11 = sxx.xy, s12 = sxx.xz, s22 = dot7(iyp, iyp);
         const float A11 = wave_sum((float)s11) * FLT_SCALE;
         const float A12 = wave_sum((float)s12) * FLT_SCALE;
         const float A22 = wave_sum((float)s22) * FLT_SCALE;
@@ -331,7 +368,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // the weights change then, and the step needs no memory access at all.  Hence two loops: the
         // outer one fetches for a new corner, the inner one steps with the column pairs held fixed.
         int have_x = INT_MIN, have_y = INT_MIN;
-        Cols cols = {};
+        Cols cols;
+#pragma unroll
+        for (int k = 0; k < 8; k++) asm("" : "=v"(cols.c[k])); // defined without a fill; read only once fetched
         int j = 0;
         bool more = a.max_count > 0;
         float flx = floorf(nx), fly = floorf(ny);
@@ -352,8 +391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 int diff[RUN];
                 sample_run(cols, w, Ineg, diff);
                 const Packed7 dp = pack7(diff); // |diff| <= 255 * 32
-                const int b1 = dot7(dp, ixp), b2 = dot7(dp, iyp);
-                const Sum2 bs = wave_sum2((float)b1, (float)b2);
+                const Dot2 bb = dot7x2(dp, ixp, iyp);
+                const Sum2 bs = wave_sum2((float)bb.xy, (float)bb.xz);
                 const float fb1 = bs.a * FLT_SCALE, fb2 = bs.b * FLT_SCALE;
                 const float dx = (A12 * fb2 - A22 * fb1) * D;
                 const float dy = (A12 * fb1 - A11 * fb2) * D;
