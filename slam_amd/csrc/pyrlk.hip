@@ -34,6 +34,7 @@ struct LkArgs {
     double eps_sq;
     float eps_lo, eps_hi; // float step^2 at or below eps_lo passes, at or above eps_hi fails, without doubles
     double min_eig_thr;
+    float min_eig_lo, min_eig_hi; // float minEig estimates outside [lo, hi] decide without the exact value
     const int *d_n; // optional: actual point count lives in device memory (<= n_per_pair)
     PairList pairs;
     int prev_off[MAX_BATCH]; // first point of pair i in prev[]
@@ -348,13 +349,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         const Dot2 sxx = dot7x2(ixp, ixp, iyp);
         const int s11 = sxx.xy, s12 = sxx.xz, s22 = dot7(iyp, iyp);
-        const float A11 = wave_sum((float)s11) * FLT_SCALE;
-        const float A12 = wave_sum((float)s12) * FLT_SCALE;
+        const Sum2 sa = wave_sum2((float)s11, (float)s12);
+        const float A11 = sa.a * FLT_SCALE, A12 = sa.b * FLT_SCALE;
         const float A22 = wave_sum((float)s22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
-        const float minEig =
-            (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if ((double)minEig < a.min_eig_thr || D < 1.1920928955078125e-07f) {
+        // minEig = (A22 + A11 - sqrt((A11 - A22)^2 + 4 A12^2)) / (2 * 21 * 21) against the threshold.
+        // The correctly rounded square root and division cost some thirty instructions, so they are
+        // only spent on values next to the threshold: the hardware square root (1 ulp) and a
+        // reciprocal multiply land within tr * 2^-18 / 882 + 2^-19 |minEig| of the exact float result.
+        const float tr = A22 + A11;
+        const float disc = (A11 - A22) * (A11 - A22) + 4.f * A12 * A12;
+        const float quick = (tr - __builtin_amdgcn_sqrtf(disc)) * (1.f / (float)(2 * WIN * WIN));
+        const float slack = tr * (1.f / (262144.f * (float)(2 * WIN * WIN)));
+        bool weak;
+        if (quick > a.min_eig_hi + slack) weak = false;
+        else if (quick < a.min_eig_lo - slack) weak = true;
+        else weak = (double)((tr - sqrtf(disc)) / (float)(2 * WIN * WIN)) < a.min_eig_thr;
+        if (weak || D < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
         }
@@ -498,6 +509,13 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
         a.eps_hi = __builtin_inff();
     }
     a.min_eig_thr = p->min_eig_thr;
+    if (p->min_eig_thr >= 1e-12 && p->min_eig_thr <= 1e12) {
+        a.min_eig_lo = (float)(p->min_eig_thr * (1.0 - 1e-5));
+        a.min_eig_hi = (float)(p->min_eig_thr * (1.0 + 1e-5));
+    } else { // unusual thresholds (zero, negative, huge, NaN): always take the exact value
+        a.min_eig_lo = -__builtin_inff();
+        a.min_eig_hi = __builtin_inff();
+    }
     a.d_n = d_n;
     a.pairs = pairs;
     for (int i = 0; i < n_pairs; i++) { a.prev_off[i] = prev_off[i]; a.next_off[i] = next_off[i]; }

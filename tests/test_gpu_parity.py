@@ -136,6 +136,28 @@ def test_lk_max_level_3_and_iteration_limits(make_ctx, oracle, klib):
         _lk_compare(go, gs, ge, oo, os_, oe)
 
 
+def test_lk_unusual_thresholds(make_ctx, oracle, klib):
+    """Thresholds outside the usual range switch the kernel's quick float tests off (zero or negative
+    minEigThreshold, epsilon 0); a threshold inside a flat region's minEig range exercises both the
+    quick accept and the quick reject; results must still be the oracle's."""
+    a, b = synth.texture_pair(640, 480, 8, 1.3, -0.6, noise=True)
+    a = a.copy(); b = b.copy()
+    a[:, :200] = (a[:, :200] // 32) * 32 + 7      # weak-texture band: small eigenvalues
+    b[:, :200] = (b[:, :200] // 32) * 32 + 7
+    ctx = make_ctx(width=640, height=480)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.build_pyramids([0, 1])
+    rng = np.random.default_rng(5)
+    pts = np.stack([rng.uniform(0, 640, 1500), rng.uniform(0, 480, 1500)], 1).astype(np.float32)
+    for thr, eps in [(0.0, 0.01), (-1.0, 0.01), (1e-13, 0.01), (1e-4, 0.0), (5e-3, 0.01), (0.02, 0.03), (0.05, 0.01), (3.0, 0.01)]:
+        go, gs, ge = ctx.pyrlk(0, 1, pts, klib.lk_params(min_eig_thr=thr, epsilon=eps))
+        oo, os_, oe = oracle.pyrlk(a, b, pts, min_eig_thr=thr, epsilon=eps, nthreads=4)
+        _lk_compare(go, gs, ge, oo, os_, oe)
+        if 5e-3 <= thr <= 0.05:
+            assert 0 < gs.sum() < len(gs)  # the threshold really splits this point set
+
+
 def test_lk_negative_remainder_weight(make_ctx, oracle, klib):
     """The fourth bilinear weight is 2^14 minus the three rounded ones and can be -1; points whose
     sub-pixel fractions trigger that must still match (signed arithmetic in the samplers)."""
