@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--max-level", type=int, default=4)
     ap.add_argument("--min-dist", type=float, default=10.0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget (0 = skip)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="contexts (each with its own stream and slots) the steps alternate between, so one "
+                         "step's pyramid build overlaps the previous step's LK tail")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
     ap.add_argument("--workload", choices=["pairs", "sequence", "ransac"], default="pairs",
                     help="pairs: the headline frame-pair stream (default); sequence: stereo tracker + pose on a "
@@ -238,12 +241,17 @@ def main():
     frames = [scene.render(f) for f in range(P + 1)]
     cfg = K.default_config(width=W, height=H, num_slots=P + 1, max_level=a.max_level, max_points=max(NF, 1024),
                            cx=scene.cx, cy=scene.cy)
-    ctx = K.Context(cfg, device=local)
+    ctxs = [K.Context(cfg, device=local) for _ in range(max(1, a.pipeline))]
+    ctx = ctxs[0]
     t_h2d = time.perf_counter()
     for s, f in enumerate(frames):
         ctx.upload_image(s, f)
     ctx.sync()
     t_h2d = time.perf_counter() - t_h2d
+    for c in ctxs[1:]:
+        for s, f in enumerate(frames):
+            c.upload_image(s, f)
+        c.sync()
     # corners of every pair's first frame, from the product detector (Shi-Tomasi, whole frame)
     gp = K.gftt_params(NF, 0.01, a.min_dist, 3, 0, 0.0)
     pts = np.zeros((P, NF, 2), np.float32)
@@ -253,38 +261,47 @@ def main():
             raise SystemExit("frame %d yields %d corners < %d; lower --min-dist" % (i, len(xy), NF))
         pts[i] = xy
     d_prev = torch.from_numpy(pts).to(dev)
-    d_next = torch.zeros_like(d_prev)
-    d_status = torch.zeros((P, NF), dtype=torch.uint8, device=dev)
-    d_err = torch.zeros((P, NF), dtype=torch.float32, device=dev)
+    outs = [(torch.zeros_like(d_prev), torch.zeros((P, NF), dtype=torch.uint8, device=dev),
+             torch.zeros((P, NF), dtype=torch.float32, device=dev)) for _ in ctxs]
+    d_next, d_status, d_err = outs[0]
     lk = K.lk_params(WIN, a.max_level)
     slots = list(range(P + 1))
     prev_slots, next_slots = slots[:-1], slots[1:]
+    step_no = [0]
 
     def step():
-        ctx.build_pyramids(slots)
-        ctx.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, d_next.data_ptr(), d_status.data_ptr(),
-                            d_err.data_ptr(), lk)
+        i = step_no[0] % len(ctxs)
+        step_no[0] += 1
+        c, (o_next, o_status, o_err) = ctxs[i], outs[i]
+        c.build_pyramids(slots)
+        c.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, o_next.data_ptr(), o_status.data_ptr(),
+                          o_err.data_ptr(), lk)
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, len(ctxs))):
         step()
     fence()
-    ctx.profile_enable(True)
-    ctx.profile_reset()
+    for c in ctxs:
+        c.profile_enable(True)
+        c.profile_reset()
     fence()
+    step_no[0] = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    k3_ms, k3_n = ctx.profile_get(K.K_PYRLK)
-    k1_ms, k1_n = ctx.profile_get(K.K_PYRDOWN)
-    ctx.profile_enable(False)
+    k3_ms = k3_n = k1_ms = k1_n = 0
+    for c in ctxs:
+        m, n = c.profile_get(K.K_PYRLK); k3_ms += m; k3_n += n
+        m, n = c.profile_get(K.K_PYRDOWN); k1_ms += m; k1_n += n
+        c.profile_enable(False)
 
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
     rec = torch.tensor([float(P * NF), float(tracked), float(P), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
