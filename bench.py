@@ -255,10 +255,18 @@ def main():
     # corners of every pair's first frame, from the product detector (Shi-Tomasi, whole frame)
     gp = K.gftt_params(NF, 0.01, a.min_dist, 3, 0, 0.0)
     pts = np.zeros((P, NF, 2), np.float32)
+    min_dist_used = a.min_dist
     for i in range(P):
+        md = a.min_dist
         (xy, _), = ctx.detect_gftt(i, [(0, 0, W, H)], gp)
-        if len(xy) < NF:
-            raise SystemExit("frame %d yields %d corners < %d; lower --min-dist" % (i, len(xy), NF))
+        while len(xy) < NF:
+            # a frame short of corners at this spacing: tighten the spacing for that frame until the
+            # detector yields the workload's count (deterministic per seed)
+            md *= 0.9
+            if md < 1.0:
+                raise SystemExit("frame %d yields %d corners < %d even at minDistance 1" % (i, len(xy), NF))
+            (xy, _), = ctx.detect_gftt(i, [(0, 0, W, H)], K.gftt_params(NF, 0.01, md, 3, 0, 0.0))
+        min_dist_used = min(min_dist_used, md)
         pts[i] = xy
     d_prev = torch.from_numpy(pts).to(dev)
     outs = [(torch.zeros_like(d_prev), torch.zeros((P, NF), dtype=torch.uint8, device=dev),
@@ -339,7 +347,9 @@ def main():
                             "maxLevel=%d (%d pyramid levels), 21x21 window, 30 it / eps 0.01" % (W, H, NF, a.max_level,
                                                                                                levels),
                 "pairs_per_step": P,
+                "pipeline_contexts": len(ctxs),
                 "features_per_pair": NF,
+                "min_distance_rank0": min_dist_used,
                 "per_gpu_sequence": "corridor seed 0x%X + rank" % a.seed,
                 "features_in_per_step": total_in,
                 "tracked_per_step": total_tracked,
