@@ -188,6 +188,29 @@ __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, cons
           "v"(acc0[6]));
     v[0] = d0 >> 9; v[1] = d1 >> 9; v[2] = d2 >> 9; v[3] = d3 >> 9; v[4] = d4 >> 9; v[5] = d5 >> 9; v[6] = d6 >> 9;
 }
+// The same with one accumulator start for all seven samples (a rounding constant).
+__device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, int acc0, int (&v)[7]) {
+    int d0, d1, d2, d3, d4, d5, d6;
+    asm("v_dot2_i32_i16 %0, %7, %15, %17\n\t"
+        "v_dot2_i32_i16 %1, %8, %15, %17\n\t"
+        "v_dot2_i32_i16 %2, %9, %15, %17\n\t"
+        "v_dot2_i32_i16 %3, %10, %15, %17\n\t"
+        "v_dot2_i32_i16 %4, %11, %15, %17\n\t"
+        "v_dot2_i32_i16 %5, %12, %15, %17\n\t"
+        "v_dot2_i32_i16 %6, %13, %15, %17\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %16, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %16, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %16, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %16, %5\n\t"
+        "v_dot2_i32_i16 %6, %14, %16, %6\n\t"
+        "s_nop 2"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6)
+        : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
+          "v"(w.wl), "v"(w.wr), "v"(acc0));
+    v[0] = d0 >> 9; v[1] = d1 >> 9; v[2] = d2 >> 9; v[3] = d3 >> 9; v[4] = d4 >> 9; v[5] = d5 >> 9; v[6] = d6 >> 9;
+}
 // int16 pairs (v0, v1), (v2, v3), (v4, v5), (v6, 0) of seven values that fit 16 bits
 struct Packed7 {
     uint32_t p[4];
@@ -304,12 +327,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         else { ox = ox * 2.f; oy = oy * 2.f; }
 
         px -= halfWin; py -= halfWin;
-        const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
+        const float fpx = floorf(px), fpy = floorf(py);
+        int ipx, ipy;
+        scalar_xy((int)fpx, (int)fpy, ipx, ipy);
         if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
             if (level == 0) { status = 0; errv = 0.f; }
             continue;
         }
-        Weights w = bilinear_weights(px - (float)ipx, py - (float)ipy);
+        Weights w = bilinear_weights(px - fpx, py - fpy);
 
         // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
         int Ineg[RUN];     // 256 - 512 * I: accumulator start of the mismatch samples
@@ -324,9 +349,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
             for (int k = 0; k <= RUN; k++) { d0[k] = dt[k]; d1[k] = db[k]; }
             {
-                const int round9[RUN] = {256, 256, 256, 256, 256, 256, 256};
                 int Iv[RUN];
-                sample_run(col_pairs(t, b), w, round9, Iv);
+                sample_run(col_pairs(t, b), w, 256, Iv);
 #pragma unroll
                 for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
             }
@@ -338,10 +362,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 cyp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
             }
             // CV_DESCALE(sum, 14) = ((sum + 2^13) >> 9) >> 5, as the low nine bits only get dropped
-            const int round14[RUN] = {1 << 13, 1 << 13, 1 << 13, 1 << 13, 1 << 13, 1 << 13, 1 << 13};
             int ixv[RUN], iyv[RUN];
-            sample_run(cxp, w, round14, ixv);
-            sample_run(cyp, w, round14, iyv);
+            sample_run(cxp, w, 1 << 13, ixv);
+            sample_run(cyp, w, 1 << 13, iyv);
 #pragma unroll
             for (int i = 0; i < RUN; i++) { ixv[i] >>= 5; iyv[i] >>= 5; }
             ixp = pack7(ixv);
