@@ -1,0 +1,111 @@
+"""Randomised differential tests of the HIP path against the CPU oracle through the C ABI: image
+sizes from tiny to medium (so the level count, the block mapping and every edge case of the padded
+planes vary), random motion, random content (including pure noise, which keeps LK iterating to its
+limit and moving its window), points inside, on and outside the image."""
+import numpy as np
+import pytest
+
+from slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _sizes(rng, n):
+    out = [(22, 22), (23, 45), (64, 48), (43, 301)]  # below / at the pyramid rule's edges, very thin
+    while len(out) < n:
+        out.append((int(rng.integers(24, 720)), int(rng.integers(24, 520))))
+    return out
+
+
+def _images(rng, w, h, kind):
+    if kind == 0:   # smooth texture, sub-pixel to several-pixel shift
+        dx, dy = rng.uniform(-6, 6, 2)
+        return synth.texture_pair(w, h, int(rng.integers(1, 1 << 30)), float(dx), float(dy), noise=True)
+    if kind == 1:   # white noise in both frames: no consistent motion, long iteration chains
+        return (rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (h, w), dtype=np.uint8))
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)   # integer translation of noise with saturated patches
+    a[: h // 3, : w // 2] = 255
+    a[h // 2:, w // 2:] = 0
+    s = int(rng.integers(-3, 4))
+    return a, np.roll(a, (s, -s), (0, 1))
+
+
+def test_pyramid_scharr_lk_random_sizes(make_ctx, oracle, klib):
+    rng = np.random.default_rng(20240611)
+    checked = 0
+    for i, (w, h) in enumerate(_sizes(rng, 14)):
+        a, b = _images(rng, w, h, i % 3)
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+        ctx = make_ctx(width=w, height=h, num_slots=2, max_points=1024)
+        ctx.upload_image(0, a)
+        ctx.upload_image(1, b)
+        ctx.build_pyramids([0, 1])
+        po = oracle.Pyramid(a, 4, 21)
+        assert ctx.pyramid_levels(0) == po.max_level, (w, h)
+        for l in range(po.max_level + 1):
+            lv = po.level(l)
+            assert np.array_equal(ctx.download_level(0, l), lv), (w, h, l)
+            assert np.array_equal(ctx.download_scharr(0, l, lv.shape[1], lv.shape[0]), po.deriv(l)), (w, h, l)
+        n = 600
+        pts = np.stack([rng.uniform(-30, w + 30, n), rng.uniform(-30, h + 30, n)], 1).astype(np.float32)
+        pts[:8] = [[0, 0], [w - 1, h - 1], [w, h], [-21, -21], [w - 0.5, 0.25], [0.25, h - 0.5], [w / 2, h / 2],
+                   [10.5, 10.5]]
+        go, gs, ge = ctx.pyrlk(0, 1, pts)
+        oo, os_, oe = oracle.pyrlk(a, b, pts, nthreads=8)
+        agree = gs == os_
+        # a status may flip where a float sum sits on a threshold; positions of agreeing points must match
+        assert agree.mean() >= 0.99, (w, h, agree.mean())
+        both = agree & (gs == 1)
+        if both.any():
+            d = np.abs(go - oo).max(1)[both]
+            de = np.abs(ge - oe)[both]
+            if i % 3 == 0:   # real motion: LK converges, everything agrees closely
+                assert d.max() <= 0.05, (w, h, d.max())
+                assert de.max() <= 0.05, (w, h, de.max())
+            else:
+                # noise: LK does not converge, so the last-bit differences of the float sums (the kernel
+                # adds 63 integer partials in a tree, the oracle 441 floats serially) grow over up to 150
+                # steps; the bulk must still agree, and the residual must agree where the position does
+                # (on white noise it changes by tens of grey levels per pixel of displacement)
+                assert np.quantile(d, 0.95) <= 0.05, (w, h, np.quantile(d, 0.95))
+                assert np.all(de <= 0.05 + 100.0 * d), (w, h, float((de - 100.0 * d).max()))
+            checked += int(both.sum())
+        lost = agree & (gs == 0)
+        assert np.array_equal(ge[lost], oe[lost])
+        ctx.close()
+    assert checked > 1500
+
+
+def test_corners_and_gates_random(make_ctx, oracle, klib):
+    rng = np.random.default_rng(77)
+    for i in range(6):
+        w, h = int(rng.integers(80, 700)), int(rng.integers(60, 500))
+        img = synth.texture_image(w, h, seed=int(rng.integers(1, 1 << 30)), periods=(31.0, 11.0, 5.0), noise=True)
+        ctx = make_ctx(width=w, height=h, num_slots=1)
+        ctx.upload_image(0, img)
+        rois = []
+        for _ in range(12):
+            rw, rh = int(rng.integers(8, min(64, w))), int(rng.integers(8, min(64, h)))
+            rois.append((int(rng.integers(0, w - rw + 1)), int(rng.integers(0, h - rh + 1)), rw, rh))
+        harris = i % 2
+        gp = klib.gftt_params(int(rng.integers(1, 120)), 0.01, float(rng.choice([1.0, 3.0, 10.0])), 3, harris,
+                              0.04 if i % 3 == 0 else 0.0)
+        got = ctx.detect_gftt(0, rois, gp)
+        for (rx, ry, rw, rh), (xy, resp) in zip(rois, got):
+            oxy, oresp = oracle.good_features(img, (rx, ry, rw, rh), gp.max_corners, gp.quality, gp.min_dist,
+                                              bool(harris), gp.harris_k)
+            oxy, oresp = np.asarray(oxy, np.float32).reshape(-1, 2), np.asarray(oresp, np.float32)
+            assert np.array_equal(xy, oxy), (w, h, rx, ry, rw, rh)
+            assert np.array_equal(resp, oresp)
+        # gates on random tracks
+        n = int(rng.integers(1, 900))
+        f1 = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)
+        f2 = f1 + rng.normal(0, 40, (n, 2)).astype(np.float32)
+        chk = f1 + rng.normal(0, 1.0, (n, 2)).astype(np.float32)
+        yth = int(rng.integers(1, 60))
+        keep = ctx.fb_gate(f1, f2, chk, yth)
+        okeep = oracle.fb_gate(f1, f2, chk, w, h, 30, 30, 100.0, yth)
+        assert np.array_equal(np.asarray(keep), np.flatnonzero(okeep))
+        ckeep = ctx.circular_gate(f1, chk)
+        assert np.array_equal(np.asarray(ckeep), np.flatnonzero(oracle.circular_gate(f1, chk)))
+        ctx.close()
