@@ -305,10 +305,11 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    k3_ms = k3_n = k1_ms = k1_n = 0
+    k3_ms = k3_n = k1_ms = k1_n = k2_ms = k2_n = 0
     for c in ctxs:
         m, n = c.profile_get(K.K_PYRLK); k3_ms += m; k3_n += n
         m, n = c.profile_get(K.K_PYRDOWN); k1_ms += m; k1_n += n
+        m, n = c.profile_get(K.K_SCHARR); k2_ms += m; k2_n += n
         c.profile_enable(False)
 
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
@@ -376,6 +377,9 @@ def main():
                 "pyr_down_u8": {"avg_ms_per_step": k1_ms / max(k1_n, 1), "images_per_step": P + 1,
                                 "algorithmic_bytes_per_image": pyr_bytes,
                                 "achieved_GBps": pyr_bytes * (P + 1) / max(k1_ms / max(k1_n, 1) * 1e-3, 1e-12) / 1e9},
+                "scharr_planes": {"avg_ms_per_step": k2_ms / max(k2_n, 1), "images_per_step": P + 1,
+                                  "algorithmic_bytes_per_image": 5 * lv_bytes,   # 1 B read + 4 B written per pixel
+                                  "achieved_GBps": 5 * lv_bytes * (P + 1) / max(k2_ms / max(k2_n, 1) * 1e-3, 1e-12) / 1e9},
                 "pyrlk_track_w21": {"avg_ms_per_step": k3_ms / max(k3_n, 1)},
             },
             "h2d_inclusive": {"value": total_tracked / world / (t_max / a.steps + t_h2d),

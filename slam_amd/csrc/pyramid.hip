@@ -107,41 +107,62 @@ __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotLi
     }
 }
 
-// calcSharrDeriv for every level of the listed slots in one launch: grid (tiles of level 0, level,
-// slot).  A thread produces four consecutive pixels (one 16-byte store of four dx|dy pairs) from
-// three rows of the padded image, whose frame supplies calcSharrDeriv's reflect-101 neighbours.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// calcSharrDeriv for every level of the listed slots in one launch: grid (row segments of level 0,
+// level, slot).  A thread produces eight consecutive pixels (two 16-byte stores of dx|dy pairs) from
+// three 16-byte row pieces of the padded image, whose frame supplies calcSharrDeriv's reflect-101
+// neighbours.  The arithmetic runs on packed int16 pairs (|values| <= 16 * 255):
+//   T = 3 (r0 + r2) + 10 r1,  dx[x] = T[x+1] - T[x-1];   D = r2 - r0,  dy[x] = 3 (D[x-1] + D[x+1]) + 10 D[x].
 // Only the interior of the plane is written; its frame stays zero (copyMakeBorder BORDER_CONSTANT).
 __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, SlotList list, int n_levels) {
     const int level = blockIdx.y;
     if (level >= n_levels) return;
     const LevelDesc L = slots[list.s[blockIdx.z]].lv[level];
-    const int qw = (L.w + 3) >> 2;                 // quads per row
-    const int q = blockIdx.x * 256 + threadIdx.x;  // quad index in raster order
-    if (q >= qw * L.h) return;
-    const int y = q / qw, x0 = (q - y * qw) * 4;
-    // bytes x0-4 .. x0+7 of rows y-1, y, y+1 (origin and pitch are multiples of 4)
-    uint32_t d[3][3];
+    const int ow = (L.w + 7) >> 3;                 // octets per row
+    const int q = blockIdx.x * 256 + threadIdx.x;  // octet index in raster order
+    if (q >= ow * L.h) return;
+    const int y = q / ow, x0 = (q - y * ow) * 8;
+    // bytes x0-4 .. x0+11 of rows y-1, y, y+1 (origin and pitch are multiples of 4); byte i is pixel x0-4+i
+    uint4 r[3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
-        d[j][0] = p[0]; d[j][1] = p[1]; d[j][2] = p[2];
-    }
-    auto B = [&](int j, int k) -> int { // pixel x0 + k, k in -1..4
-        const int b = k + 4;
-        return (int)((d[j][b >> 2] >> (8 * (b & 3))) & 0xffu);
+    for (int j = 0; j < 3; j++)
+        r[j] = *reinterpret_cast<const uint4 *>(L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
+    auto pr = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(hi, lo, sel)); };
+    // pairs (b[3+2j], b[4+2j]), j = 0..4, and (b[4+2j], b[5+2j]), j = 0..3, zero-extended
+    auto odd = [&](const uint4 &d, i16x2 (&o)[5]) {
+        o[0] = pr(d.y, d.x, 0x0c040c03u); o[1] = pr(d.y, d.y, 0x0c020c01u); o[2] = pr(d.z, d.y, 0x0c040c03u);
+        o[3] = pr(d.z, d.z, 0x0c020c01u); o[4] = pr(d.w, d.z, 0x0c040c03u);
     };
-    uint32_t out[4];
+    auto even = [&](const uint4 &d, i16x2 (&e)[4]) {
+        e[0] = pr(d.y, d.y, 0x0c010c00u); e[1] = pr(d.y, d.y, 0x0c030c02u);
+        e[2] = pr(d.z, d.z, 0x0c010c00u); e[3] = pr(d.z, d.z, 0x0c030c02u);
+    };
+    i16x2 o0[5], o1[5], o2[5], e0[4], e2[4];
+    odd(r[0], o0); odd(r[1], o1); odd(r[2], o2);
+    even(r[0], e0); even(r[2], e2);
+    const i16x2 three = {3, 3}, ten = {10, 10};
+    i16x2 T[5], Do[5];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int dx = 3 * ((B(0, k + 1) - B(0, k - 1)) + (B(2, k + 1) - B(2, k - 1))) + 10 * (B(1, k + 1) - B(1, k - 1));
-        const int dy = 3 * ((B(2, k - 1) - B(0, k - 1)) + (B(2, k + 1) - B(0, k + 1))) + 10 * (B(2, k) - B(0, k));
-        out[k] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+    for (int j = 0; j < 5; j++) {
+        T[j] = three * (o0[j] + o2[j]) + ten * o1[j];
+        Do[j] = o2[j] - o0[j];
+    }
+    uint32_t out[8];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {   // pixels x0 + 2j, x0 + 2j + 1
+        const i16x2 dx = T[j + 1] - T[j];
+        const i16x2 dy = three * (Do[j] + Do[j + 1]) + ten * (e2[j] - e0[j]);
+        const uint32_t ux = __builtin_bit_cast(uint32_t, dx), uy = __builtin_bit_cast(uint32_t, dy);
+        out[2 * j] = __builtin_amdgcn_perm(uy, ux, 0x05040100u);
+        out[2 * j + 1] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
     }
     uint32_t *o = L.dorigin + (ptrdiff_t)y * L.pitch + x0;
-    if (x0 + 3 < L.w) {
-        *reinterpret_cast<uint4 *>(o) = make_uint4(out[0], out[1], out[2], out[3]);
+    if (x0 + 7 < L.w) {
+        reinterpret_cast<uint4 *>(o)[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        reinterpret_cast<uint4 *>(o)[1] = make_uint4(out[4], out[5], out[6], out[7]);
     } else {
-        for (int k = 0; k < 4 && x0 + k < L.w; k++) o[k] = out[k];
+        for (int k = 0; k < 8 && x0 + k < L.w; k++) o[k] = out[k];
     }
 }
 
@@ -218,8 +239,8 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
         KTLVO_HIP(ctx, hipGetLastError());
         {
             ProfScope ps2(ctx, KTLVO_K_SCHARR);
-            const int quads0 = ((ctx->lw[0] + 3) / 4) * ctx->lh[0];
-            dim3 grid((quads0 + 255) / 256, top + 1, list.n);
+            const int octets0 = ((ctx->lw[0] + 7) / 8) * ctx->lh[0];
+            dim3 grid((octets0 + 255) / 256, top + 1, list.n);
             hipLaunchKernelGGL(scharr_planes, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, top + 1);
             KTLVO_HIP(ctx, hipGetLastError());
         }
