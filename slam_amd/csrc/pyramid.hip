@@ -26,84 +26,99 @@ __global__ __launch_bounds__(256) void ingest_pad_u8(const SlotDesc *slots, int 
     L.origin[(ptrdiff_t)y * L.pitch + x] = src[(size_t)reflect101(y, L.h) * stride + reflect101(x, L.w)];
 }
 
-constexpr int TW = 64; // output tile
-constexpr int TH = 16;
-constexpr int SR = 2 * TH + 4;  // source rows per tile (36)
-constexpr int SD = (2 * TW + 8) / 4; // source dwords per tile row (34): bytes [2*tx0-4, 2*tx0+132)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// Plane pointers come out of a descriptor in memory, so the compiler would treat them as generic
+// (flat) addresses; they are global.
+typedef __attribute__((address_space(1))) uint8_t *gbyte;
+typedef const __attribute__((address_space(1))) uint8_t *gcbyte;
+typedef __attribute__((address_space(1))) uint32_t *gword;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PD_ROWS = 4;         // output rows per thread
+constexpr int PD_TW = 256;         // output columns per workgroup (64 lanes x 4 pixels)
+constexpr int PD_TH = 4 * PD_ROWS; // output rows per workgroup (4 waves)
+
+// Horizontal 1-4-6-4-1 at four even source columns, as two packed uint16 pairs.  d holds the 16
+// source bytes starting four bytes left of the first output's centre: output k is centred on byte
+// 4 + 2k.  Sums stay below 16 * 255, so uint16 lanes are exact.
+__device__ __forceinline__ void pyr_h4(const u32x4 &d, u16x2 &h01, u16x2 &h23) {
+    auto pr = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel)); };
+    // v_perm_b32 selectors: bytes 0-3 of the second operand, 4-7 of the first, 0x0c = zero
+    const u16x2 e0 = pr(d.y, d.x, 0x0c040c02u); // (b2, b4)
+    const u16x2 e1 = pr(d.y, d.y, 0x0c020c00u); // (b4, b6)
+    const u16x2 e2 = pr(d.z, d.y, 0x0c040c02u); // (b6, b8)
+    const u16x2 e3 = pr(d.z, d.z, 0x0c020c00u); // (b8, b10)
+    const u16x2 e4 = pr(d.w, d.z, 0x0c040c02u); // (b10, b12)
+    const u16x2 o0 = pr(d.y, d.x, 0x0c050c03u); // (b3, b5)
+    const u16x2 o1 = pr(d.y, d.y, 0x0c030c01u); // (b5, b7)
+    const u16x2 o2 = pr(d.z, d.y, 0x0c050c03u); // (b7, b9)
+    const u16x2 o3 = pr(d.z, d.z, 0x0c030c01u); // (b9, b11)
+    const u16x2 six = {6, 6}, four = {4, 4};
+    h01 = e0 + e2 + six * e1 + four * (o0 + o1);
+    h23 = e2 + e4 + six * e3 + four * (o2 + o3);
+}
+
+// Stores the four pixels v (byte k = pixel x + k) of one row and their reflect-101 copies that fall
+// into the left / right frame: pixel x goes to -x (1 <= x <= PAD) and to 2 (w - 1) - x (if that lies
+// in [w, w + PAD)).  Whole mirrored quads go out as one byte-reversed word at an address that is
+// in general not word aligned (memcpy lets the compiler pick the store), ragged ones bytewise.
+__device__ __forceinline__ void pyr_store_row(gbyte row, int x, int w, uint32_t v) {
+    const int nvalid = w - x < 4 ? w - x : 4;
+    if (nvalid == 4) *(gword)(row + x) = v;
+    else for (int k = 0; k < nvalid; k++) row[x + k] = (uint8_t)(v >> (8 * k));
+    const uint32_t rev = __builtin_amdgcn_perm(0u, v, 0x00010203u);
+    if (x <= PAD) { // left frame: pixels x .. x+3 -> -x-3 .. -x (pixel 0 lands on itself)
+        if (nvalid == 4 && x + 3 <= PAD) __builtin_memcpy(row - x - 3, &rev, 4);
+        else for (int k = 0; k < nvalid; k++) if (x + k >= 1 && x + k <= PAD) row[-(x + k)] = (uint8_t)(v >> (8 * k));
+    }
+    const int m = 2 * (w - 1); // right frame: pixel p -> m - p, valid for w - 1 - PAD <= p <= w - 2
+    if (x + 3 >= w - 1 - PAD) {
+        if (nvalid == 4 && x >= w - 1 - PAD && x + 3 <= w - 1) __builtin_memcpy(row + m - x - 3, &rev, 4); // pixel w-1 lands on itself
+        else for (int k = 0; k < nvalid; k++) {
+            const int p = x + k;
+            if (p <= w - 2 && m - p < w + PAD) row[m - p] = (uint8_t)(v >> (8 * k));
+        }
+    }
+}
 
 // One level of cv::pyrDown: dst(x,y) = (sum_{i,j} k_i k_j src(2x+i, 2y+j) + 128) >> 8, k = [1 4 6 4 1].
 // The source frame already holds the reflect-101 continuation, which is what pyrDown's own
-// borderInterpolate yields.
+// borderInterpolate yields.  A thread makes a 4 x PD_ROWS block of outputs: it walks down
+// 2 * PD_ROWS + 3 source rows (one 16-byte load each), keeps their horizontal sums in registers as
+// packed uint16 pairs and combines five of them per output row, so nothing goes through LDS.  Each
+// output row is also written to the rows of the top / bottom frame it is mirrored to.
 __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotList list, int src_level) {
     const SlotDesc &S = slots[list.s[blockIdx.z]];
     const LevelDesc src = S.lv[src_level];
     const LevelDesc dst = S.lv[src_level + 1];
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const int tid = threadIdx.x;
+    const int ox = blockIdx.x * PD_TW + (threadIdx.x & 63) * 4;
+    const int oy0 = blockIdx.y * PD_TH + (threadIdx.x >> 6) * PD_ROWS;
+    if (ox >= dst.w || oy0 >= dst.h) return;
 
-    __shared__ uint32_t tile[SR][SD + 1];
-    __shared__ uint16_t hbuf[SR][TW];
-
-    // source rows 2*ty0-2 .. +35, bytes 2*tx0-4 .. +135 (dword aligned: origin and pitch are)
-    for (int i = tid; i < SR * SD; i += 256) {
-        const int r = i / SD, c = i - r * SD;
-        const int sy = 2 * ty0 - 2 + r, sx = 2 * tx0 - 4 + 4 * c;
-        uint32_t v = 0;
-        if (sy < src.h + PAD && sx + 3 < src.w + PAD) // upper-left is always inside the frame (PAD >= 4)
-            v = *reinterpret_cast<const uint32_t *>(src.origin + (ptrdiff_t)sy * src.pitch + sx);
-        tile[r][c] = v;
-    }
-    __syncthreads();
-
-    // horizontal 1-4-6-4-1 at even source columns: two outputs per item from three dwords
-    for (int i = tid; i < SR * (TW / 2); i += 256) {
-        const int r = i / (TW / 2), j = i - r * (TW / 2);
-        const uint32_t d0 = tile[r][j], d1 = tile[r][j + 1], d2 = tile[r][j + 2];
-        // output x = 2j is centred on tile byte 4j+4, x = 2j+1 on byte 4j+6
-        const uint32_t b2 = (d0 >> 16) & 0xff, b3 = d0 >> 24;
-        const uint32_t c0 = d1 & 0xff, c1 = (d1 >> 8) & 0xff, c2 = (d1 >> 16) & 0xff, c3 = d1 >> 24;
-        const uint32_t e0 = d2 & 0xff;
-        hbuf[r][2 * j] = (uint16_t)(b2 + 4 * b3 + 6 * c0 + 4 * c1 + c2);
-        hbuf[r][2 * j + 1] = (uint16_t)(c0 + 4 * c1 + 6 * c2 + 4 * c3 + e0);
-    }
-    __syncthreads();
-
-    // vertical pass: thread -> row y, four consecutive x
-    const int y = tid >> 4, xq = (tid & 15) * 4;
-    const int oy = ty0 + y, ox = tx0 + xq;
-    if (oy >= dst.h || ox >= dst.w) return;
-    uint32_t out[4];
+    constexpr int NS = 2 * PD_ROWS + 3;
+    u16x2 h01[NS], h23[NS];
+    const int last_row = src.h + PAD - 1; // source rows past the level's last output row are not used: keep them inside the plane
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = xq + k;
-        const uint32_t v = hbuf[2 * y][x] + 4 * hbuf[2 * y + 1][x] + 6 * hbuf[2 * y + 2][x] +
-                           4 * hbuf[2 * y + 3][x] + hbuf[2 * y + 4][x];
-        out[k] = (v + 128) >> 8;
+    for (int r = 0; r < NS; r++) {
+        int sy = 2 * oy0 - 2 + r;
+        sy = sy < last_row ? sy : last_row;
+        const u32x4 d = *(const __attribute__((address_space(1))) u32x4 *)((gcbyte)src.origin + (ptrdiff_t)sy * src.pitch + 2 * ox - 4);
+        pyr_h4(d, h01[r], h23[r]);
     }
-    uint8_t *row = dst.origin + (ptrdiff_t)oy * dst.pitch;
-    if (ox + 3 < dst.w) {
-        *reinterpret_cast<uint32_t *>(row + ox) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
-    } else {
-        for (int k = 0; k < 4 && ox + k < dst.w; k++) row[ox + k] = (uint8_t)out[k];
-    }
-
-    // reflect-101 copies into the frame (edge tiles only)
-    const bool ynear = oy <= PAD || oy >= dst.h - 1 - PAD;
-    const bool xnear = ox <= PAD || ox + 3 >= dst.w - 1 - PAD;
-    if (!(ynear || xnear)) return;
-    int ys[3], ny = 0;
-    ys[ny++] = oy;
-    if (oy >= 1 && oy <= PAD) ys[ny++] = -oy;
-    if (oy <= dst.h - 2 && 2 * (dst.h - 1) - oy < dst.h + PAD) ys[ny++] = 2 * (dst.h - 1) - oy;
-    for (int k = 0; k < 4 && ox + k < dst.w; k++) {
-        const int x = ox + k;
-        int xs[3], nx = 0;
-        xs[nx++] = x;
-        if (x >= 1 && x <= PAD) xs[nx++] = -x;
-        if (x <= dst.w - 2 && 2 * (dst.w - 1) - x < dst.w + PAD) xs[nx++] = 2 * (dst.w - 1) - x;
-        for (int a = 0; a < ny; a++)
-            for (int b = 0; b < nx; b++)
-                if (a | b) dst.origin[(ptrdiff_t)ys[a] * dst.pitch + xs[b]] = (uint8_t)out[k];
+    const u16x2 six = {6, 6}, four = {4, 4}, half = {128, 128};
+#pragma unroll
+    for (int j = 0; j < PD_ROWS; j++) {
+        const int oy = oy0 + j;
+        if (oy >= dst.h) break;
+        // vertical sums stay below 256 * 255
+        const u16x2 v01 = (h01[2 * j] + h01[2 * j + 4] + six * h01[2 * j + 2] + four * (h01[2 * j + 1] + h01[2 * j + 3]) + half) >> 8;
+        const u16x2 v23 = (h23[2 * j] + h23[2 * j + 4] + six * h23[2 * j + 2] + four * (h23[2 * j + 1] + h23[2 * j + 3]) + half) >> 8;
+        const uint32_t v = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v23), __builtin_bit_cast(uint32_t, v01), 0x06040200u);
+        const gbyte org = (gbyte)dst.origin;
+        pyr_store_row(org + (ptrdiff_t)oy * dst.pitch, ox, dst.w, v);
+        if (oy >= 1 && oy <= PAD) pyr_store_row(org - (ptrdiff_t)oy * dst.pitch, ox, dst.w, v);
+        const int my = 2 * (dst.h - 1) - oy;
+        if (oy <= dst.h - 2 && my < dst.h + PAD) pyr_store_row(org + (ptrdiff_t)my * dst.pitch, ox, dst.w, v);
     }
 }
 
@@ -124,17 +139,17 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
     if (q >= ow * L.h) return;
     const int y = q / ow, x0 = (q - y * ow) * 8;
     // bytes x0-4 .. x0+11 of rows y-1, y, y+1 (origin and pitch are multiples of 4); byte i is pixel x0-4+i
-    uint4 r[3];
+    u32x4 r[3];
 #pragma unroll
     for (int j = 0; j < 3; j++)
-        r[j] = *reinterpret_cast<const uint4 *>(L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
+        r[j] = *(const __attribute__((address_space(1))) u32x4 *)((gcbyte)L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
     auto pr = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(hi, lo, sel)); };
     // pairs (b[3+2j], b[4+2j]), j = 0..4, and (b[4+2j], b[5+2j]), j = 0..3, zero-extended
-    auto odd = [&](const uint4 &d, i16x2 (&o)[5]) {
+    auto odd = [&](const u32x4 &d, i16x2 (&o)[5]) {
         o[0] = pr(d.y, d.x, 0x0c040c03u); o[1] = pr(d.y, d.y, 0x0c020c01u); o[2] = pr(d.z, d.y, 0x0c040c03u);
         o[3] = pr(d.z, d.z, 0x0c020c01u); o[4] = pr(d.w, d.z, 0x0c040c03u);
     };
-    auto even = [&](const uint4 &d, i16x2 (&e)[4]) {
+    auto even = [&](const u32x4 &d, i16x2 (&e)[4]) {
         e[0] = pr(d.y, d.y, 0x0c010c00u); e[1] = pr(d.y, d.y, 0x0c030c02u);
         e[2] = pr(d.z, d.z, 0x0c010c00u); e[3] = pr(d.z, d.z, 0x0c030c02u);
     };
@@ -157,10 +172,11 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
         out[2 * j] = __builtin_amdgcn_perm(uy, ux, 0x05040100u);
         out[2 * j + 1] = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
     }
-    uint32_t *o = L.dorigin + (ptrdiff_t)y * L.pitch + x0;
+    const gword o = (gword)L.dorigin + (ptrdiff_t)y * L.pitch + x0;
     if (x0 + 7 < L.w) {
-        reinterpret_cast<uint4 *>(o)[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        reinterpret_cast<uint4 *>(o)[1] = make_uint4(out[4], out[5], out[6], out[7]);
+        typedef __attribute__((address_space(1))) u32x4 *gquad;
+        ((gquad)o)[0] = u32x4{out[0], out[1], out[2], out[3]};
+        ((gquad)o)[1] = u32x4{out[4], out[5], out[6], out[7]};
     } else {
         for (int k = 0; k < 8 && x0 + k < L.w; k++) o[k] = out[k];
     }
@@ -232,7 +248,7 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
         {
             ProfScope ps(ctx, KTLVO_K_PYRDOWN);
             for (int l = 0; l < top; l++) {
-                dim3 grid((ctx->lw[l + 1] + TW - 1) / TW, (ctx->lh[l + 1] + TH - 1) / TH, list.n);
+                dim3 grid((ctx->lw[l + 1] + PD_TW - 1) / PD_TW, (ctx->lh[l + 1] + PD_TH - 1) / PD_TH, list.n);
                 hipLaunchKernelGGL(pyr_down_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, l);
             }
         }
