@@ -393,6 +393,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             continue;
         }
         D = 1.f / D;
+        // FLT_SCALE is a power of two, so scaling b1, b2 by it (as OpenCV does before forming the step)
+        // commutes with every rounding below and can be applied to D once per level instead
+        const float Ds = D * FLT_SCALE;
 
         // ---- Gauss-Newton iterations -----------------------------------------------------------
         float nx = ox - halfWin, ny = oy - halfWin;
@@ -427,9 +430,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const Packed7 dp = pack7(diff); // |diff| <= 255 * 32
                 const Dot2 bb = dot7x2(dp, ixp, iyp);
                 const Sum2 bs = wave_sum2((float)bb.xy, (float)bb.xz);
-                const float fb1 = bs.a * FLT_SCALE, fb2 = bs.b * FLT_SCALE;
-                const float dx = (A12 * fb2 - A22 * fb1) * D;
-                const float dy = (A12 * fb1 - A11 * fb2) * D;
+                const float dx = (A12 * bs.b - A22 * bs.a) * Ds;
+                const float dy = (A12 * bs.a - A11 * bs.b) * Ds;
                 nx += dx; ny += dy;
                 ox = nx + halfWin; oy = ny + halfWin;
                 // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
