@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=63, help="frame pairs per step (<= 63)")
+    ap.add_argument("--pairs", type=int, default=127, help="frame pairs per step (<= 127)")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
@@ -233,12 +233,12 @@ def main():
             dist.destroy_process_group()
         return
     W, H, P, NF = a.width, a.height, a.pairs, a.features
-    assert 1 <= P <= 63
+    assert 1 <= P <= 127
     pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
 
     # ---- synthetic input: one sequence per rank -----------------------------------------------
     scene = synth.CorridorScene(W, H, seed=shard.rank_seed(a.seed, rank))
-    frames = [scene.render(f) for f in range(P + 1)]
+    frames = synth.render_corridor_frames(W, H, shard.rank_seed(a.seed, rank), P + 1, workers=8)
     cfg = K.default_config(width=W, height=H, num_slots=P + 1, max_level=a.max_level, max_points=max(NF, 1024),
                            cx=scene.cx, cy=scene.cy)
     ctxs = [K.Context(cfg, device=local) for _ in range(max(1, a.pipeline))]

@@ -17,7 +17,7 @@ constexpr int MAX_LEVELS = 8;
 // reflect-101 continuation of the level (what cv::buildOpticalFlowPyramid's copyMakeBorder
 // produces for `win` pixels), so the LK kernel never needs border index arithmetic.
 constexpr int PAD = 32;
-constexpr int MAX_BATCH = 64; // slots / pairs passed by value to one launch
+constexpr int MAX_BATCH = 128; // slots / pairs passed by value to one launch
 
 struct LevelDesc {
     uint8_t *origin;   // address of pixel (0,0)

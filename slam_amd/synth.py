@@ -143,3 +143,41 @@ class CorridorScene:
 
     def stereo_pair(self, frame, noise=True):
         return self.render(frame, False, noise=noise), self.render(frame, True, noise=noise)
+
+
+def render_corridor_frames(width, height, seed, n_frames, workers=8):
+    """Frames 0 .. n_frames-1 of CorridorScene(width, height, seed) (left camera), rendered by `workers`
+    fresh interpreter processes that import nothing but numpy and this file (safe to call from a
+    process that holds a GPU context; no fork of it takes place)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    workers = max(1, min(workers, n_frames))
+    if workers == 1:
+        sc = CorridorScene(width, height, seed=seed)
+        return [sc.render(f) for f in range(n_frames)]
+    here = os.path.abspath(__file__)
+    with tempfile.TemporaryDirectory(prefix="ktlvo_frames_") as tmp:
+        procs = []
+        for k in range(workers):
+            out = os.path.join(tmp, "part%d.npy" % k)
+            procs.append((out, subprocess.Popen([sys.executable, here, str(width), str(height), str(seed), str(k),
+                                                 str(workers), str(n_frames), out])))
+        parts = []
+        for out, pr in procs:
+            if pr.wait() != 0:
+                raise RuntimeError("frame renderer failed")
+            parts.append(np.load(out))
+    frames = [None] * n_frames
+    for k, part in enumerate(parts):
+        for i, f in enumerate(range(k, n_frames, workers)):
+            frames[f] = np.ascontiguousarray(part[i])
+    return frames
+
+
+if __name__ == "__main__":
+    import sys
+    w_, h_, seed_, first_, stride_, n_, out_ = sys.argv[1:8]
+    sc_ = CorridorScene(int(w_), int(h_), seed=int(seed_))
+    np.save(out_, np.stack([sc_.render(f) for f in range(int(first_), int(n_), int(stride_))]))

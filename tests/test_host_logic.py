@@ -90,3 +90,14 @@ def test_gather_world_size_2_gloo():
     # gathered results equal what two single-process runs produce
     single = [shard.gather_records(torch.tensor(recs[r]), 1)[0] for r in range(2)]
     assert np.array_equal(np.stack(single), recs)
+
+
+def test_parallel_frame_renderer_matches_serial():
+    """bench.py renders its input frames in helper processes; they must be the serial renderer's."""
+    from slam_amd import synth
+    frames = synth.render_corridor_frames(160, 96, 0x5EED0002, 5, workers=3)
+    scene = synth.CorridorScene(160, 96, seed=0x5EED0002)
+    assert len(frames) == 5
+    for f, img in enumerate(frames):
+        assert img.dtype == np.uint8 and img.shape == (96, 160)
+        assert np.array_equal(img, scene.render(f))

@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from slam_amd import shard, synth  # noqa: E402
 
-W, H, P, NF, SEED = 1241, 376, 63, 2000, 0x5EED0002
+W, H, P, NF, SEED = 1241, 376, 127, 2000, 0x5EED0002
 
 
 def render(args):
