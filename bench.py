@@ -187,21 +187,41 @@ def cpu_baseline(frames, pts, max_level, budget_s):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
     n_pairs = min(len(frames) - 1, 4)
-    tracked, t0, reps = 0, time.perf_counter(), 0
-    while True:
-        for i in range(n_pairs):
-            pa = O.Pyramid(frames[i], max_level, WIN, True)
-            pb = O.Pyramid(frames[i + 1], max_level, WIN, False)
-            _, st, _ = O.pyrlk(pa, pb, pts[i], WIN, max_level, nthreads=cores)
-            tracked += int(st.sum())
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 1000:
-            break
-    return {"value": tracked / el, "unit": "tracked features/s", "cores": cores, "kind": "port",
+
+    def timed(threads, budget):
+        tracked, t0, reps = 0, time.perf_counter(), 0
+        while True:
+            for i in range(n_pairs):
+                pa = O.Pyramid(frames[i], max_level, WIN, True)
+                pb = O.Pyramid(frames[i + 1], max_level, WIN, False)
+                _, st, _ = O.pyrlk(pa, pb, pts[i], WIN, max_level, nthreads=threads)
+                tracked += int(st.sum())
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or reps >= 1000:
+                return tracked / el, reps, el
+
+    v_all, reps, el = timed(cores, budget_s)
+    v_one, reps1, el1 = timed(1, max(1.0, budget_s * 0.3))
+    # Gauss-Newton steps per level of the first pair (levels listed from level 0 up)
+    it, _ = O.lk_iterations(O.Pyramid(frames[0], max_level, WIN, True), O.Pyramid(frames[1], max_level, WIN, False),
+                            pts[0], max_level=max_level)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": v_all, "unit": "tracked features/s", "cores": cores, "kind": "port",
             "sample": "first %d frame pairs x %d features of the same workload, %d repetitions, %.1f s; "
                       "pyramids + Scharr + LK per pair (one calcOpticalFlowPyrLK each), points range-split "
-                      "over %d threads" % (n_pairs, pts.shape[1], reps, el, cores)}
+                      "over %d threads" % (n_pairs, pts.shape[1], reps, el, cores),
+            "single_thread": {"value": v_one, "cores": 1, "sample": "%d repetitions, %.1f s" % (reps1, el1)},
+            "cpu_model": model,
+            "lk_iterations_per_level_mean": [float(x) for x in it.mean(1)],
+            "lk_iterations_per_feature_mean": float(it.sum(0).mean())}
 
 
 def main():
@@ -313,6 +333,27 @@ def main():
         c.profile_enable(False)
 
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
+    # the same step with maxLevel 3 (4 pyramid images), in case "4-level" is read that way
+    ml3 = None
+    if world == 1 and a.max_level == 4:
+        lk3 = K.lk_params(WIN, 3)
+        n3 = max(3, a.steps // 4)
+
+        def step3():
+            ctx.build_pyramids(slots, max_level=3)
+            ctx.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, d_next.data_ptr(),
+                                d_status.data_ptr(), d_err.data_ptr(), lk3)
+        step3()
+        fence()
+        t3 = time.perf_counter()
+        for _ in range(n3):
+            step3()
+        fence()
+        t3 = time.perf_counter() - t3
+        tr3 = int(d_status.sum().item())
+        ml3 = {"value": tr3 * n3 / t3, "unit": "tracked features/s", "steps": n3, "tracked_per_step": tr3}
+        ctx.build_pyramids(slots)   # leave the slots as the main run built them
+        fence()
     rec = torch.tensor([float(P * NF), float(tracked), float(P), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
                        dtype=torch.float64, device=dev)
     t_max = shard.max_over_ranks(elapsed, dev, world)
@@ -368,6 +409,8 @@ def main():
                 "traffic_source": traffic_src,
                 "bytes_model_per_feature": bpf,
                 # compulsory-unique traffic of one pair: both pyramids read once + point I/O
+                "bytes_rocprof_per_feature": (traffic / feats_per_launch) if traffic else None,
+                "lds_bank_conflict_rate": 0.0,   # the kernel has no LDS instruction (SQ_INSTS_LDS = 0 in profiles/)
                 "bytes_floor_per_feature": (2 * lv_bytes + 29 * NF) / NF,
                 "avg_launch_ms": k3_avg_s * 1e3,
                 "launches": int(k3_n),
@@ -388,6 +431,8 @@ def main():
             "per_rank": [{"features_in": r[0], "tracked": r[1], "k3_ms": r[3], "k1_ms": r[5], "elapsed_s": r[7]}
                          for r in recs.tolist()],
         }
+        if ml3 is not None:
+            out["max_level_3"] = ml3
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames, pts, a.max_level, a.cpu_seconds)
         print(json.dumps(out))
