@@ -192,6 +192,37 @@ int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, const uint8_t 
 int ktlvo_estimate_pose(ktlvo_ctx *ctx, const ktlvo_depth_point *last, const ktlvo_image_point *cur,
                         int n, float T_local[16], float T_global[16], int *n_inliers);
 
+/* ---- wire format ---------------------------------------------------------------------------- */
+/* ROS 1 serialisation (little endian, as roscpp puts it on the wire) of the three messages the
+ * reference publishes, so that its downstream nodes can consume this library's output unchanged:
+ *   /image_points_last  sensor_msgs/PointCloud2 of DepthPoint  featureTracking.cpp:656-659, visualOdometry.cpp:332-335
+ *   /image_points_cur   sensor_msgs/PointCloud2 of ImagePoint  featureTracking.cpp:661-664, visualOdometry.cpp:337-340
+ *   /local_transform    ktl_vo/transform_msg                   visualOdometry.cpp:316-330, msg/transform_msg.msg:1-2
+ * The point clouds are what pcl::toROSMsg makes of a pcl::PointCloud filled by push_back: height 1,
+ * width n, one field per registered member (pointDefinition.h:23-26, 36-42; float -> FLOAT32 = 7,
+ * int -> INT32 = 5, count 1), little endian, point_step = sizeof(point), row_step = point_step * n,
+ * data = the point array, is_dense = 1.  Host-only functions: no context, no GPU work. */
+typedef struct {
+    uint32_t seq;          /* roscpp numbers messages per publisher; the reference leaves it to roscpp */
+    uint32_t stamp_sec;    /* header.stamp, see ktlvo_ros_time_from_sec */
+    uint32_t stamp_nsec;
+    const char *frame_id;  /* NULL = "" (the reference never sets it) */
+} ktlvo_ros_header;
+/* ros::Time().fromSec(t) as the reference stamps its messages (featureTracking.cpp:658). t >= 0. */
+int ktlvo_ros_time_from_sec(double t, uint32_t *sec, uint32_t *nsec);
+/* Serialised sizes in bytes (0 if an argument is invalid). */
+size_t ktlvo_wire_size_image_points(int n, const ktlvo_ros_header *h);
+size_t ktlvo_wire_size_depth_points(int n, const ktlvo_ros_header *h);
+size_t ktlvo_wire_size_transform(const ktlvo_ros_header *h);
+/* Write the message body into out[0 .. cap); *written = bytes used.  KTLVO_ERR_CAPACITY if cap is
+ * too small (nothing is written then). */
+int ktlvo_wire_image_points(const ktlvo_image_point *pts, int n, const ktlvo_ros_header *h, uint8_t *out,
+                            size_t cap, size_t *written);
+int ktlvo_wire_depth_points(const ktlvo_depth_point *pts, int n, const ktlvo_ros_header *h, uint8_t *out,
+                            size_t cap, size_t *written);
+/* T = the T_local of ktlvo_estimate_pose, row-major (visualOdometry.cpp:316-322). */
+int ktlvo_wire_transform(const float T[16], const ktlvo_ros_header *h, uint8_t *out, size_t cap, size_t *written);
+
 /* ---- profiling ------------------------------------------------------------------------------ */
 /* With profiling on, every launch of the kernels listed in the enum above is bracketed by
  * hipEvents on the context's stream; ktlvo_profile_get synchronises and returns the summed

@@ -62,6 +62,10 @@ class Roi(C.Structure):
     _fields_ = [("x", C.c_int), ("y", C.c_int), ("w", C.c_int), ("h", C.c_int)]
 
 
+class RosHeader(C.Structure):
+    _fields_ = [("seq", C.c_uint32), ("stamp_sec", C.c_uint32), ("stamp_nsec", C.c_uint32), ("frame_id", C.c_char_p)]
+
+
 IMAGE_POINT = np.dtype([("u", "<f4"), ("v", "<f4"), ("ind", "<i4")])
 DEPTH_POINT = np.dtype([("u", "<f4"), ("v", "<f4"), ("depth", "<f4"), ("label", "<i4"), ("ind", "<i4"),
                         ("newKeyFrame", "<i4")])
@@ -97,6 +101,13 @@ SIGNATURES = {
     "ktlvo_solve_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _f, _d, _vp, _vp, _vp, _ip, _ip]),
     "ktlvo_track_stereo_frame": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ip, _ip]),
     "ktlvo_estimate_pose": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _ip]),
+    "ktlvo_ros_time_from_sec": (_i, [_d, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ktlvo_wire_size_image_points": (C.c_size_t, [_i, C.POINTER(RosHeader)]),
+    "ktlvo_wire_size_depth_points": (C.c_size_t, [_i, C.POINTER(RosHeader)]),
+    "ktlvo_wire_size_transform": (C.c_size_t, [C.POINTER(RosHeader)]),
+    "ktlvo_wire_image_points": (_i, [_vp, _i, C.POINTER(RosHeader), _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ktlvo_wire_depth_points": (_i, [_vp, _i, C.POINTER(RosHeader), _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ktlvo_wire_transform": (_i, [_vp, C.POINTER(RosHeader), _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "ktlvo_profile_enable": (_i, [_vp, _i]),
     "ktlvo_profile_reset": (_i, [_vp]),
     "ktlvo_profile_get": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
@@ -120,6 +131,56 @@ lib = _load()
 
 def strerror(status):
     return lib.ktlvo_strerror(status).decode()
+
+
+# -- wire format (host-only entry points, no context)
+def ros_time_from_sec(t):
+    sec, nsec = C.c_uint32(), C.c_uint32()
+    rc = lib.ktlvo_ros_time_from_sec(t, C.byref(sec), C.byref(nsec))
+    if rc != OK:
+        raise KtlvoError(rc, "ktlvo_ros_time_from_sec")
+    return sec.value, nsec.value
+
+
+def _ros_header(seq, stamp, frame_id):
+    sec, nsec = ros_time_from_sec(stamp) if not isinstance(stamp, tuple) else stamp
+    return RosHeader(seq, sec, nsec, frame_id.encode() if frame_id is not None else None)
+
+
+def _wire(need, put, where):
+    buf = np.zeros(max(need, 1), np.uint8)
+    written = C.c_size_t()
+    rc = put(_ptr(buf), need, C.byref(written))
+    if rc != OK:
+        raise KtlvoError(rc, where)
+    return buf[:written.value].tobytes()
+
+
+def wire_image_points(pts, seq=0, stamp=0.0, frame_id=None):
+    """ROS 1 body of the sensor_msgs/PointCloud2 the reference publishes on /image_points_cur."""
+    pts = np.ascontiguousarray(pts, IMAGE_POINT)
+    h = _ros_header(seq, stamp, frame_id)
+    return _wire(lib.ktlvo_wire_size_image_points(len(pts), C.byref(h)),
+                 lambda out, cap, wr: lib.ktlvo_wire_image_points(_ptr(pts), len(pts), C.byref(h), out, cap, wr),
+                 "ktlvo_wire_image_points")
+
+
+def wire_depth_points(pts, seq=0, stamp=0.0, frame_id=None):
+    """ROS 1 body of the sensor_msgs/PointCloud2 the reference publishes on /image_points_last."""
+    pts = np.ascontiguousarray(pts, DEPTH_POINT)
+    h = _ros_header(seq, stamp, frame_id)
+    return _wire(lib.ktlvo_wire_size_depth_points(len(pts), C.byref(h)),
+                 lambda out, cap, wr: lib.ktlvo_wire_depth_points(_ptr(pts), len(pts), C.byref(h), out, cap, wr),
+                 "ktlvo_wire_depth_points")
+
+
+def wire_transform(T, seq=0, stamp=0.0, frame_id=None):
+    """ROS 1 body of the ktl_vo/transform_msg the reference publishes on /local_transform."""
+    T = np.ascontiguousarray(T, np.float32).reshape(16)
+    h = _ros_header(seq, stamp, frame_id)
+    return _wire(lib.ktlvo_wire_size_transform(C.byref(h)),
+                 lambda out, cap, wr: lib.ktlvo_wire_transform(_ptr(T), C.byref(h), out, cap, wr),
+                 "ktlvo_wire_transform")
 
 
 def default_config(**kw):
