@@ -68,8 +68,8 @@ def measured_traffic(kernel, waves_per_launch):
         except (OSError, ValueError):
             continue
         if e and "hbm_bytes_per_launch" in e and int(e.get("SQ_WAVES", -1)) == int(waves_per_launch):
-            return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+            return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), e
+    return None, None, None
 
 
 def parse():
@@ -370,7 +370,17 @@ def main():
         for _ in range(levels):
             lv_bytes += w_ * h_
             w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
-        traffic, traffic_src = measured_traffic("pyrlk_track_w21", feats_per_launch)
+        traffic, traffic_src, pmc = measured_traffic("pyrlk_track_w21", feats_per_launch)
+        # what the kernel is really limited by: vector-ALU issue.  A wave64 VALU instruction holds a
+        # SIMD's ALU for 4 cycles; 256 CUs x 4 SIMDs; shader clock measured with s_memtime under
+        # this kernel: 2.39 GHz.  Instruction count from the same PMC summary as `traffic`.
+        valu = None
+        if pmc and pmc.get("SQ_INSTS_VALU") and k3_avg_s > 0:
+            valu = {"insts_per_feature": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
+                    "vmem_insts_per_feature": pmc.get("SQ_INSTS_VMEM", 0.0) / pmc["SQ_WAVES"],
+                    "issue_busy_frac": pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.39e9 * k3_avg_s),
+                    "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.39 GHz x kernel time); "
+                            "counters from " + traffic_src}
         out = {
             "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
             "value": value,
@@ -410,6 +420,7 @@ def main():
                 "bytes_model_per_feature": bpf,
                 # compulsory-unique traffic of one pair: both pyramids read once + point I/O
                 "bytes_rocprof_per_feature": (traffic / feats_per_launch) if traffic else None,
+                "valu": valu,
                 "lds_bank_conflict_rate": 0.0,   # the kernel has no LDS instruction (SQ_INSTS_LDS = 0 in profiles/)
                 "bytes_floor_per_feature": (2 * lv_bytes + 29 * NF) / NF,
                 "avg_launch_ms": k3_avg_s * 1e3,
