@@ -113,23 +113,38 @@ __global__ __launch_bounds__(256) void corner_nms_compact(const RoiDev *rois, co
                                                           unsigned long long *cand, int *cand_cnt) {
     const RoiDev R = rois[blockIdx.z];
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < 1 || y < 1 || x >= R.w - 1 || y >= R.h - 1) return;
-    const double maxVal = (double)ord2f(roi_max[blockIdx.z]);
-    const float thr = (float)(maxVal * quality);
-    const float *e = resp + R.off + y * R.w + x;
-    const float v = e[0] > thr ? e[0] : 0.f;
-    if (v == 0.f) return;
-    float m = v;
+    bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1;
+    float v = 0.f;
+    if (keep) {
+        const double maxVal = (double)ord2f(roi_max[blockIdx.z]);
+        const float thr = (float)(maxVal * quality);
+        const float *e = resp + R.off + y * R.w + x;
+        v = e[0] > thr ? e[0] : 0.f;
+        keep = v != 0.f;
+        if (keep) {
+            float m = v;
 #pragma unroll
-    for (int j = -1; j <= 1; j++)
+            for (int j = -1; j <= 1; j++)
 #pragma unroll
-        for (int i = -1; i <= 1; i++) {
-            const float t = e[j * R.w + i];
-            m = fmaxf(m, t > thr ? t : 0.f);
+                for (int i = -1; i <= 1; i++) {
+                    const float t = e[j * R.w + i];
+                    m = fmaxf(m, t > thr ? t : 0.f);
+                }
+            keep = v == m;
         }
-    if (v != m) return;
-    const int o = atomicAdd(&cand_cnt[blockIdx.z], 1);
-    cand[R.off + o] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * R.w + x);
+    }
+    // One counter bump per wave instead of one per candidate (a textured frame has thousands of
+    // local maxima, all of one ROI): the wave's candidates take consecutive places.  Their order in
+    // the list does not matter, the keys are sorted later and are unique.
+    const unsigned long long votes = __ballot(keep);
+    if (!keep) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)votes) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&cand_cnt[blockIdx.z], __popcll(votes));
+    base = __shfl(base, leader);
+    const int place = base + __popcll(votes & ((1ull << lane) - 1ull));
+    cand[R.off + place] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * R.w + x);
 }
 
 struct SelArgs {
