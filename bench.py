@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="contexts (each with its own stream and slots) the steps alternate between, so one "
                          "step's pyramid build overlaps the previous step's LK tail")
+    ap.add_argument("--skip-secondary", action="store_true",
+                    help="leave out the maxLevel-3 run (profiling passes: one launch shape per kernel)")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
     ap.add_argument("--workload", choices=["pairs", "sequence", "ransac"], default="pairs",
                     help="pairs: the headline frame-pair stream (default); sequence: stereo tracker + pose on a "
@@ -335,7 +337,7 @@ def main():
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
     # the same step with maxLevel 3 (4 pyramid images), in case "4-level" is read that way
     ml3 = None
-    if world == 1 and a.max_level == 4:
+    if world == 1 and a.max_level == 4 and not a.skip_secondary:
         lk3 = K.lk_params(WIN, 3)
         n3 = max(3, a.steps // 4)
 

@@ -116,14 +116,20 @@ __device__ __forceinline__ Sum2 wave_sum2(float a, float b) {
 struct Weights {
     uint32_t wl, wr;
 };
-__device__ __forceinline__ Weights bilinear_weights(float a, float b) {
-    // OpenCV: iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14), iw10 = cvRound((1-a)*b*2^14).
-    // Scaling by 2^14 is exact, so it can be folded into one factor first; adding 2^23 rounds a
-    // float in [0, 2^23) to the nearest-even integer and leaves it in the low mantissa bits.
-    const float A = 1.f - a, B = (1.f - b) * 16384.f, bs = b * 16384.f;
-    const uint32_t m00 = __float_as_uint(A * B + 8388608.f);
-    const uint32_t m01 = __float_as_uint(a * B + 8388608.f);
-    const uint32_t m10 = __float_as_uint(A * bs + 8388608.f);
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Weights bilinear_weights(float x, float y, float floor_x, float floor_y) {
+    // OpenCV: a = x - floor(x), b = y - floor(y); iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14),
+    // iw10 = cvRound((1-a)*b*2^14).  Scaling by 2^14 is exact and commutes with the roundings of 1 - b
+    // and of the products, so it is applied to b first; adding 2^23 rounds a float in [0, 2^23) to the
+    // nearest-even integer and leaves it in the low mantissa bits.  Written on float pairs so that the
+    // compiler emits packed instructions: X = (a, b 2^14), Y = (1 - a, (1 - b) 2^14), and one
+    // v_pk_mul_f32 with crossed halves yields (a * Y.y, X.y * (1 - a)).
+    const f32x2 scale = {1.f, 16384.f}, magic = {8388608.f, 8388608.f};
+    const f32x2 X = (f32x2{x, y} - f32x2{floor_x, floor_y}) * scale;
+    const f32x2 Y = scale - X;
+    const f32x2 cross = __builtin_shufflevector(X, X, 0, 1) * __builtin_shufflevector(Y, Y, 1, 0) + magic;
+    const uint32_t m00 = __float_as_uint(Y.x * Y.y + 8388608.f);
+    const uint32_t m01 = __float_as_uint(cross.x), m10 = __float_as_uint(cross.y);
     // 16384 - iw00 - iw01 - iw10 in the low 16 bits (the 0x4B000000 exponent fields cancel mod 2^32)
     const uint32_t m11 = (16384u + 3u * 0x4B000000u) - (m00 + m01 + m10);
     Weights w;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (level == 0) { status = 0; errv = 0.f; }
             continue;
         }
-        Weights w = bilinear_weights(px - fpx, py - fpy);
+        Weights w = bilinear_weights(px, py, fpx, fpy);
 
         // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
         int Ineg[RUN];     // 256 - 512 * I: accumulator start of the mismatch samples
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 have_x = inx; have_y = iny;
             }
             for (;;) {
-                w = bilinear_weights(nx - flx, ny - fly);
+                w = bilinear_weights(nx, ny, flx, fly);
                 int diff[RUN];
                 sample_run(cols, w, Ineg, diff);
                 const Packed7 dp = pack7(diff); // |diff| <= 255 * 32
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 status = 0;
             } else {
-                w = bilinear_weights(fx - (float)inx, fy - (float)iny);
+                w = bilinear_weights(fx, fy, (float)inx, (float)iny);
                 if (inx != have_x || iny != have_y) {
                     const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
                     cols = col_pairs(load_run8(Jbase, e0), load_run8(Jbase, e0 + pitch));
