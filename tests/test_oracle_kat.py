@@ -84,6 +84,58 @@ def test_lk_recovers_subpixel_shift(shift):
     assert np.array_equal(out, out2) and np.array_equal(st, st2) and np.array_equal(err, err2)
 
 
+def _float_lk(prev, nxt, pts, levels=5, win=21, iters=30, eps=0.01):
+    """Plain float64 pyramidal Lucas-Kanade as published (Bouguet): Gaussian 1-4-6-4-1 pyramid, Scharr
+    derivatives of the previous image, bilinear sampling, 21x21 window centred on the point, Gauss-Newton
+    steps from the coarsest level down.  No fixed point, no OpenCV-specific rounding."""
+    from scipy import ndimage as ndi
+    k = np.array([1, 4, 6, 4, 1]) / 16.0
+
+    def down(a):
+        a = ndi.correlate1d(ndi.correlate1d(a, k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
+        return a[::2, ::2]
+
+    P, N = [prev.astype(np.float64)], [nxt.astype(np.float64)]
+    for _ in range(levels - 1):
+        P.append(down(P[-1])); N.append(down(N[-1]))
+    out = []
+    h = (win - 1) / 2
+    oy, ox = np.mgrid[-h:h + 1, -h:h + 1]
+    for (x, y) in pts:
+        g = np.zeros(2)
+        for l in range(levels - 1, -1, -1):
+            I, J = P[l], N[l]
+            Ix = ndi.correlate1d(ndi.correlate1d(I, [-1, 0, 1], axis=1, mode="mirror"), [3, 10, 3], axis=0, mode="mirror") / 32
+            Iy = ndi.correlate1d(ndi.correlate1d(I, [-1, 0, 1], axis=0, mode="mirror"), [3, 10, 3], axis=1, mode="mirror") / 32
+            px, py = x / 2 ** l, y / 2 ** l
+            samp = lambda A, cx, cy: ndi.map_coordinates(A, [oy + cy, ox + cx], order=1, mode="mirror")
+            i0, ix, iy = samp(I, px, py), samp(Ix, px, py), samp(Iy, px, py)
+            G = np.array([[np.sum(ix * ix), np.sum(ix * iy)], [np.sum(ix * iy), np.sum(iy * iy)]])
+            for _ in range(iters):
+                d = samp(J, px + g[0], py + g[1]) - i0
+                step = -np.linalg.solve(G, [np.sum(d * ix), np.sum(d * iy)])
+                g += step
+                if step @ step <= eps * eps:
+                    break
+            if l:
+                g *= 2
+        out.append([x + g[0], y + g[1]])
+    return np.array(out)
+
+
+def test_lk_against_float_restatement():
+    """The fixed-point oracle and a float64 textbook LK land on the same positions (to a few
+    hundredths of a pixel) on smooth texture with a 3.3 / -1.7 px shift."""
+    a, b = synth.texture_pair(320, 240, 21, 3.3, -1.7, noise=False)
+    rng = np.random.default_rng(4)
+    pts = np.stack([rng.uniform(40, 280, 40), rng.uniform(40, 200, 40)], 1).astype(np.float32)
+    oo, st, _ = O.pyrlk(a, b, pts)
+    ref = _float_lk(a, b, pts)
+    ok = st == 1
+    assert ok.mean() > 0.9
+    assert np.abs(oo - ref)[ok].max() < 0.03, np.abs(oo - ref)[ok].max()
+
+
 def test_lk_status_rules():
     a, b = synth.texture_pair(320, 240, 5, 1.0, 0.5)
     a[100:, 150:] = 128
@@ -111,6 +163,28 @@ def test_corner_response_closed_form():
     assert abs(x - 20) <= 1 and abs(y - 20) <= 1
     xy, resp = O.good_features(img, None, 10, 0.01, 10.0, True, 0.0)
     assert len(xy) >= 1 and abs(xy[0, 0] - 20) <= 1 and abs(xy[0, 1] - 20) <= 1
+
+
+def test_corner_response_against_scipy_evaluation():
+    """cornerHarris / cornerMinEigenVal as published: Sobel 3x3 scaled by 1 / (255 * 4 * blockSize) = 1/3060
+    (8-bit input, aperture 3, block 3), unnormalised 3x3 box sums of dx^2, dxdy, dy^2, then
+    det - k tr^2 or the smaller eigenvalue.  Evaluated independently with scipy.ndimage in float64
+    ('mirror' is reflect-101); the oracle works in float32 with double box sums."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(8)
+    img = (ndi.gaussian_filter(rng.uniform(0, 255, (70, 90)), 1.5) * 1.0).clip(0, 255).astype(np.uint8)
+    f = img.astype(np.float64)
+    sx = ndi.correlate1d(ndi.correlate1d(f, [-1, 0, 1], axis=1, mode="mirror"), [1, 2, 1], axis=0, mode="mirror") / 3060.0
+    sy = ndi.correlate1d(ndi.correlate1d(f, [-1, 0, 1], axis=0, mode="mirror"), [1, 2, 1], axis=1, mode="mirror") / 3060.0
+    box = lambda a: ndi.correlate(a, np.ones((3, 3)), mode="mirror")
+    a, b, c = box(sx * sx), box(sx * sy), box(sy * sy)
+    for k in (0.0, 0.04):
+        want = a * c - b * b - k * (a + c) ** 2
+        got = O.corner_response(img, None, True, k).astype(np.float64)
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max() + 1e-12
+    want = (a + c) / 2 - np.sqrt(((a - c) / 2) ** 2 + b * b)
+    got = O.corner_response(img, None, False, 0.0).astype(np.float64)
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max() + 1e-12
 
 
 def test_good_features_min_distance_and_order():
