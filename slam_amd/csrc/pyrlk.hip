@@ -171,7 +171,7 @@ __device__ __forceinline__ Cols col_pairs(const Run8 &t, const Run8 &b) {
 // + (acc0[i] - 256) / 512.  With acc0 = 256 this is the sample itself; with acc0 = 256 - 512 * I it is
 // sample - I at no extra cost (the subtrahend is a multiple of 2^9, so it commutes with the shift).
 // Signed dots: the remainder weight w11 can be -1 when the three rounded weights sum to 16385.
-__device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, const int (&acc0)[7], int (&v)[7]) {
+__device__ __forceinline__ void sample_sums(const Cols &k, const Weights &w, const int (&acc0)[7], int (&d)[7]) {
     int d0, d1, d2, d3, d4, d5, d6;
     asm("v_dot2_i32_i16 %0, %7, %15, %17\n\t"
         "v_dot2_i32_i16 %1, %8, %15, %18\n\t"
@@ -192,9 +192,17 @@ __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, cons
         : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
           "v"(w.wl), "v"(w.wr), "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]),
           "v"(acc0[6]));
-    v[0] = d0 >> 9; v[1] = d1 >> 9; v[2] = d2 >> 9; v[3] = d3 >> 9; v[4] = d4 >> 9; v[5] = d5 >> 9; v[6] = d6 >> 9;
+    d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = d4; d[5] = d5; d[6] = d6;
 }
-// The same with one accumulator start for all seven samples (a rounding constant).
+__device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, const int (&acc0)[7], int (&v)[7]) {
+    int d[7];
+    sample_sums(k, w, acc0, d);
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = d[i] >> 9;
+}
+// The same with one accumulator start for all seven samples (a rounding constant) and the descale
+// shift as a parameter.
+template <int SHIFT>
 __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, int acc0, int (&v)[7]) {
     int d0, d1, d2, d3, d4, d5, d6;
     asm("v_dot2_i32_i16 %0, %7, %15, %17\n\t"
@@ -215,7 +223,8 @@ __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, int 
         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6)
         : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
           "v"(w.wl), "v"(w.wr), "v"(acc0));
-    v[0] = d0 >> 9; v[1] = d1 >> 9; v[2] = d2 >> 9; v[3] = d3 >> 9; v[4] = d4 >> 9; v[5] = d5 >> 9; v[6] = d6 >> 9;
+    v[0] = d0 >> SHIFT; v[1] = d1 >> SHIFT; v[2] = d2 >> SHIFT; v[3] = d3 >> SHIFT; v[4] = d4 >> SHIFT; v[5] = d5 >> SHIFT;
+    v[6] = d6 >> SHIFT;
 }
 // int16 pairs (v0, v1), (v2, v3), (v4, v5), (v6, 0) of seven values that fit 16 bits
 struct Packed7 {
@@ -227,6 +236,20 @@ __device__ __forceinline__ Packed7 pack7(const int (&v)[7]) {
     r.p[1] = __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u);
     r.p[2] = __builtin_amdgcn_perm((uint32_t)v[5], (uint32_t)v[4], 0x05040100u);
     r.p[3] = (uint32_t)v[6] & 0xFFFFu;
+    return r;
+}
+// pack7 of (d[i] >> 9) for sums |d[i]| < 2^23: bytes 1-2 of a sum are d >> 8 as an exact int16, so one
+// v_perm_b32 packs two of them and one packed arithmetic shift by 1 finishes both (two instructions
+// per pair instead of three).
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Packed7 pack7_descale9(const int (&d)[7]) {
+    Packed7 r;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const i16x2 h = __builtin_bit_cast(i16x2, __builtin_amdgcn_perm((uint32_t)d[2 * j + 1], (uint32_t)d[2 * j], 0x06050201u));
+        r.p[j] = __builtin_bit_cast(uint32_t, h >> (short)1);
+    }
+    r.p[3] = ((uint32_t)d[6] >> 9) & 0xFFFFu;
     return r;
 }
 // (sum of x[i] * y[i], sum of x[i] * z[i]) over the seven values, exact in int32
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             for (int k = 0; k <= RUN; k++) { d0[k] = dt[k]; d1[k] = db[k]; }
             {
                 int Iv[RUN];
-                sample_run(col_pairs(t, b), w, 256, Iv);
+                sample_run<9>(col_pairs(t, b), w, 256, Iv);
 #pragma unroll
                 for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
             }
@@ -367,12 +390,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 cxp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x05040100u);
                 cyp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
             }
-            // CV_DESCALE(sum, 14) = ((sum + 2^13) >> 9) >> 5, as the low nine bits only get dropped
-            int ixv[RUN], iyv[RUN];
-            sample_run(cxp, w, 1 << 13, ixv);
-            sample_run(cyp, w, 1 << 13, iyv);
-#pragma unroll
-            for (int i = 0; i < RUN; i++) { ixv[i] >>= 5; iyv[i] >>= 5; }
+            int ixv[RUN], iyv[RUN]; // CV_DESCALE(sum, 14)
+            sample_run<14>(cxp, w, 1 << 13, ixv);
+            sample_run<14>(cyp, w, 1 << 13, iyv);
             ixp = pack7(ixv);
             iyp = pack7(iyv);
         }
@@ -431,9 +451,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             for (;;) {
                 w = bilinear_weights(nx, ny, flx, fly);
-                int diff[RUN];
-                sample_run(cols, w, Ineg, diff);
-                const Packed7 dp = pack7(diff); // |diff| <= 255 * 32
+                int dsum[RUN];
+                sample_sums(cols, w, Ineg, dsum);
+                const Packed7 dp = pack7_descale9(dsum); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
                 const Dot2 bb = dot7x2(dp, ixp, iyp);
                 const Sum2 bs = wave_sum2((float)bb.xy, (float)bb.xz);
                 const float dx = (A12 * bs.b - A22 * bs.a) * Ds;
