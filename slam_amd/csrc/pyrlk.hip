@@ -151,6 +151,23 @@ __device__ __forceinline__ Run8 load_run8(const uint8_t *base, uint32_t off) {
     r.hi = __builtin_amdgcn_alignbyte(d2, d1, off & 3u);
     return r;
 }
+// The same in two steps, so that the fetch can be issued long before its data is needed.
+struct Raw12 {
+    uint32_t d0, d1, d2;
+};
+__device__ __forceinline__ Raw12 fetch_run8(const uint8_t *base, uint32_t off) {
+    typedef const __attribute__((address_space(1))) uint8_t *gptr8;
+    gptr32 q = (gptr32)((gptr8)base + (off & ~3u));
+    Raw12 r;
+    r.d0 = q[0]; r.d1 = q[1]; r.d2 = q[2];
+    return r;
+}
+__device__ __forceinline__ Run8 align_run8(const Raw12 &w, uint32_t off) {
+    Run8 r;
+    r.lo = __builtin_amdgcn_alignbyte(w.d1, w.d0, off & 3u);
+    r.hi = __builtin_amdgcn_alignbyte(w.d2, w.d1, off & 3u);
+    return r;
+}
 // byte K of the top run and byte K of the bottom run, zero-extended into an int16 pair
 template <int K>
 __device__ __forceinline__ uint32_t col_pair(const Run8 &t, const Run8 &b) {
@@ -365,6 +382,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         Weights w = bilinear_weights(px, py, fpx, fpy);
 
+        // The first step's search rows do not depend on the template, only on the position handed
+        // down from the level above: their fetch goes out together with the template's, which saves
+        // one dependent memory round trip per level.
+        float nx = ox - halfWin, ny = oy - halfWin;
+        float flx = floorf(nx), fly = floorf(ny);
+        int inx, iny;
+        scalar_xy((int)flx, (int)fly, inx, iny);
+        const bool first_inside = !(inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h);
+        // (unconditional, from a corner clamped into the accepted range when the real one is outside:
+        // a conditional fetch would need its registers merged with defaults, which waits for the data)
+        const int cjx = min(max(inx, -WIN), J.w - 1), cjy = min(max(iny, -WIN), J.h - 1);
+        uint32_t je = lane_off + (uint32_t)(cjy * pitch + cjx);
+        Raw12 jt = fetch_run8(Jbase, je), jb = fetch_run8(Jbase, je + pitch);
+
         // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
         int Ineg[RUN];     // 256 - 512 * I: accumulator start of the mismatch samples
         Packed7 ixp, iyp;  // the template's derivatives as int16 pairs
@@ -424,7 +455,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const float Ds = D * FLT_SCALE;
 
         // ---- Gauss-Newton iterations -----------------------------------------------------------
-        float nx = ox - halfWin, ny = oy - halfWin;
         float pdx = 0.f, pdy = 0.f;
         // The rows fetched for one step serve the following steps as long as the window's integer
         // corner stays put, which is the rule once the first step or two of a level are done: only
@@ -436,19 +466,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int k = 0; k < 8; k++) asm("" : "=v"(cols.c[k])); // defined without a fill; read only once fetched
         int j = 0;
         bool more = a.max_count > 0;
-        float flx = floorf(nx), fly = floorf(ny);
-        int inx, iny;
-        scalar_xy((int)flx, (int)fly, inx, iny);
+        bool fetched = first_inside; // the rows for (inx, iny) are in jt, jb already
         while (more) {
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 if (level == 0) status = 0;
                 break;
             }
-            {
-                const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
-                cols = col_pairs(load_run8(Jbase, e0), load_run8(Jbase, e0 + pitch));
-                have_x = inx; have_y = iny;
+            if (!fetched) {
+                je = lane_off + (uint32_t)(iny * pitch + inx);
+                jt = fetch_run8(Jbase, je);
+                jb = fetch_run8(Jbase, je + pitch);
             }
+            fetched = false;
+            cols = col_pairs(align_run8(jt, je), align_run8(jb, je)); // pitch is a multiple of 4: both rows shift alike
+            have_x = inx; have_y = iny;
             for (;;) {
                 w = bilinear_weights(nx, ny, flx, fly);
                 int dsum[RUN];
