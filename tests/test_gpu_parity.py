@@ -231,6 +231,39 @@ def test_lk_batch_equals_single_calls(make_ctx, klib):
         assert np.array_equal(e, de[i].cpu().numpy())
 
 
+@pytest.mark.parametrize("n_pairs,n", [(8, 5), (11, 333), (19, 64), (128, 9)])
+def test_lk_batch_block_mapping(make_ctx, klib, n_pairs, n):
+    """Pair counts around the kernel's grouping of pairs by 8 (full groups, groups plus left-over
+    pairs, the launch capacity) and point counts that are not multiples of the 4 features of a
+    workgroup: every pair's results equal a single-pair call's."""
+    import torch
+    W, H = 320, 200
+    ctx = make_ctx(width=W, height=H, num_slots=5)
+    for s in range(5):
+        ctx.upload_image(s, synth.texture_image(W, H, 41, dx=0.9 * s, dy=0.3 * s))
+    ctx.build_pyramids(list(range(5)))
+    rng = np.random.default_rng(n_pairs)
+    prev = [int(x) for x in rng.integers(0, 5, n_pairs)]
+    nxt = [int(x) for x in rng.integers(0, 5, n_pairs)]
+    pts = np.stack([rng.uniform(0, W, (n_pairs, n)), rng.uniform(0, H, (n_pairs, n))], 2).astype(np.float32)
+    dp = torch.from_numpy(pts).cuda()
+    dn = torch.zeros_like(dp)
+    ds = torch.full((n_pairs, n), 7, dtype=torch.uint8, device="cuda")
+    de = torch.zeros((n_pairs, n), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pyrlk_batch_dev(prev, nxt, dp.data_ptr(), n, dn.data_ptr(), ds.data_ptr(), de.data_ptr(), klib.lk_params())
+    ctx.sync()
+    gn, gs, ge = dn.cpu().numpy(), ds.cpu().numpy(), de.cpu().numpy()
+    for i in range(n_pairs):
+        o, st, e = ctx.pyrlk(prev[i], nxt[i], pts[i])
+        assert np.array_equal(o, gn[i]) and np.array_equal(st, gs[i]) and np.array_equal(e, ge[i]), i
+    if n_pairs == 128:
+        with pytest.raises(klib.KtlvoError) as ei:
+            ctx.pyrlk_batch_dev(prev + [0], nxt + [1], dp.data_ptr(), n, dn.data_ptr(), ds.data_ptr(), de.data_ptr(),
+                                klib.lk_params())
+        assert ei.value.status == klib.ERR_CAPACITY
+
+
 # ---------------------------------------------------------------- corners ---------------------
 def _same_corner_set(gxy, gresp, oxy, oresp):
     assert gxy.shape == oxy.shape
