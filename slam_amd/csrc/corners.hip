@@ -108,43 +108,66 @@ __global__ __launch_bounds__(256) void corner_response_tile(const SlotDesc *slot
     if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(&roi_max[blockIdx.z], f2ord(vmax));
 }
 
+// A workgroup covers 64 x 16 pixels of one ROI.  Candidates are counted per wave (ballot), the four
+// waves' counts meet in LDS, and the workgroup takes its places in the ROI's list with ONE global
+// atomic: returning atomics on a single address serialise in L2 (about 12 ns each), which made a
+// textured whole frame (thousands of local maxima, one counter) cost 60 us when every wave bumped it.
+// The order of candidates in the list does not matter: the keys are sorted later and are unique.
+constexpr int NMS_ROWS = 16;
 __global__ __launch_bounds__(256) void corner_nms_compact(const RoiDev *rois, const float *resp,
                                                           const unsigned *roi_max, double quality,
                                                           unsigned long long *cand, int *cand_cnt) {
     const RoiDev R = rois[blockIdx.z];
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1;
-    float v = 0.f;
-    if (keep) {
-        const double maxVal = (double)ord2f(roi_max[blockIdx.z]);
-        const float thr = (float)(maxVal * quality);
-        const float *e = resp + R.off + y * R.w + x;
-        v = e[0] > thr ? e[0] : 0.f;
-        keep = v != 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const double maxVal = (double)ord2f(roi_max[blockIdx.z]);
+    const float thr = (float)(maxVal * quality);
+    __shared__ int wave_cnt[4][NMS_ROWS / 4];
+    __shared__ int block_base;
+    unsigned long long votes[NMS_ROWS / 4];
+    float vals[NMS_ROWS / 4];
+#pragma unroll
+    for (int k = 0; k < NMS_ROWS / 4; k++) { // wave w takes rows w, w + 4, ...
+        const int y = blockIdx.y * NMS_ROWS + wave + 4 * k;
+        bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1;
+        float v = 0.f;
         if (keep) {
-            float m = v;
+            const float *e = resp + R.off + y * R.w + x;
+            v = e[0] > thr ? e[0] : 0.f;
+            keep = v != 0.f;
+            if (keep) {
+                float m = v;
 #pragma unroll
-            for (int j = -1; j <= 1; j++)
+                for (int j = -1; j <= 1; j++)
 #pragma unroll
-                for (int i = -1; i <= 1; i++) {
-                    const float t = e[j * R.w + i];
-                    m = fmaxf(m, t > thr ? t : 0.f);
-                }
-            keep = v == m;
+                    for (int i = -1; i <= 1; i++) {
+                        const float t = e[j * R.w + i];
+                        m = fmaxf(m, t > thr ? t : 0.f);
+                    }
+                keep = v == m;
+            }
         }
+        vals[k] = v;
+        votes[k] = __ballot(keep);
+        if (lane == 0) wave_cnt[wave][k] = __popcll(votes[k]);
     }
-    // One counter bump per wave instead of one per candidate (a textured frame has thousands of
-    // local maxima, all of one ROI): the wave's candidates take consecutive places.  Their order in
-    // the list does not matter, the keys are sorted later and are unique.
-    const unsigned long long votes = __ballot(keep);
-    if (!keep) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)votes) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&cand_cnt[blockIdx.z], __popcll(votes));
-    base = __shfl(base, leader);
-    const int place = base + __popcll(votes & ((1ull << lane) - 1ull));
-    cand[R.off + place] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(y * R.w + x);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int k = 0; k < NMS_ROWS / 4; k++) { const int c = wave_cnt[w][k]; wave_cnt[w][k] = total; total += c; }
+        block_base = total ? atomicAdd(&cand_cnt[blockIdx.z], total) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NMS_ROWS / 4; k++) {
+        if (!((votes[k] >> lane) & 1ull)) continue;
+        const int y = blockIdx.y * NMS_ROWS + wave + 4 * k;
+        const int place = block_base + wave_cnt[wave][k] + __popcll(votes[k] & ((1ull << lane) - 1ull));
+        cand[R.off + place] = ((unsigned long long)__float_as_uint(vals[k]) << 32) | (unsigned)(y * R.w + x);
+    }
 }
 
 struct SelArgs {
@@ -403,7 +426,7 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
     if (rc != KTLVO_OK) return rc;
     KTLVO_HIP(ctx, hipMemsetAsync(w.d_cnt, 0, 4 * (size_t)n_roi, ctx->stream));
     KTLVO_HIP(ctx, hipMemsetAsync(w.d_overflow, 0, 4, ctx->stream));
-    dim3 grid((maxw + 63) / 64, (maxh + 3) / 4, n_roi);
+    dim3 grid((maxw + 63) / 64, (maxh + NMS_ROWS - 1) / NMS_ROWS, n_roi);
     hipLaunchKernelGGL(corner_nms_compact, grid, dim3(256), 0, ctx->stream, w.d_rois, w.d_resp, w.d_max, p->quality,
                        w.d_cand, w.d_cnt);
     KTLVO_HIP(ctx, hipGetLastError());
