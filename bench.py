@@ -255,7 +255,7 @@ def main():
             dist.destroy_process_group()
         return
     W, H, P, NF = a.width, a.height, a.pairs, a.features
-    assert 1 <= P <= 127
+    assert 1 <= P <= 127   # the synthetic corridor (120 m, 0.8 m per frame) ends after about 130 frames
     pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
 
     # ---- synthetic input: one sequence per rank -----------------------------------------------

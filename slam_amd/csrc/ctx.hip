@@ -85,7 +85,7 @@ extern "C" int ktlvo_default_config(ktlvo_config *c) {
 }
 
 extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
-    if (!cfg || cfg->width <= 0 || cfg->height <= 0 || cfg->num_slots <= 0 || cfg->max_level < 0 ||
+    if (!cfg || cfg->width <= 0 || cfg->height <= 0 || cfg->num_slots <= 0 || cfg->num_slots > 65536 || cfg->max_level < 0 ||
         cfg->max_level >= MAX_LEVELS || cfg->win < 3 || cfg->win + 2 > PAD || cfg->max_points <= 0 ||
         cfg->max_batch_pairs <= 0 || cfg->max_batch_pairs > MAX_BATCH)
         return nullptr;

@@ -17,7 +17,7 @@ constexpr int MAX_LEVELS = 8;
 // reflect-101 continuation of the level (what cv::buildOpticalFlowPyramid's copyMakeBorder
 // produces for `win` pixels), so the LK kernel never needs border index arithmetic.
 constexpr int PAD = 32;
-constexpr int MAX_BATCH = 128; // slots / pairs passed by value to one launch
+constexpr int MAX_BATCH = 256; // slots / pairs passed by value to one launch (kernel arguments are limited to 4 KiB)
 
 struct LevelDesc {
     uint8_t *origin;   // address of pixel (0,0)
@@ -31,9 +31,9 @@ struct SlotList {
     int n;
     int s[MAX_BATCH];
 };
-struct PairList {
-    int prev[MAX_BATCH];
-    int next[MAX_BATCH];
+struct PairList { // slot ids; ktlvo_create limits num_slots to 65536
+    uint16_t prev[MAX_BATCH];
+    uint16_t next[MAX_BATCH];
 };
 
 struct Profiler {

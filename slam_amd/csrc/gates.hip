@@ -173,9 +173,10 @@ int device_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float 
                             int y_threshold, float *d_f2, float *d_chk, int *d_keep_idx, int *d_n_keep,
                             const Gather &g) {
     ktlvo_lk_params p = {ctx->cfg.win, ctx->cfg.max_level, 30, 0.01, 1e-4};
+    if (!slot_ok(ctx, slot_1) || !slot_ok(ctx, slot_2)) return KTLVO_ERR_INVALID;
     PairList fw, bw;
-    fw.prev[0] = slot_1; fw.next[0] = slot_2;
-    bw.prev[0] = slot_2; bw.next[0] = slot_1;
+    fw.prev[0] = (uint16_t)slot_1; fw.next[0] = (uint16_t)slot_2;
+    bw.prev[0] = (uint16_t)slot_2; bw.next[0] = (uint16_t)slot_1;
     const int zero = 0;
     int rc = launch_pyrlk_ex(ctx, fw, 1, d_f1, &zero, d_f2, &zero, ctx->d_status, ctx->d_err, n_cap, d_n, &p); // :205
     if (rc != KTLVO_OK) return rc;

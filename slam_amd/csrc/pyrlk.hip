@@ -621,15 +621,19 @@ extern "C" int ktlvo_pyrlk_batch_dev(ktlvo_ctx *ctx, const int *prev_slots, cons
     if (n_pairs > ctx->cfg.max_batch_pairs) return KTLVO_ERR_CAPACITY;
     if (n_pairs == 0) return KTLVO_OK;
     PairList pl;
-    for (int i = 0; i < n_pairs; i++) { pl.prev[i] = prev_slots[i]; pl.next[i] = next_slots[i]; }
+    for (int i = 0; i < n_pairs; i++) {
+        if (!slot_ok(ctx, prev_slots[i]) || !slot_ok(ctx, next_slots[i])) return KTLVO_ERR_INVALID; // before narrowing
+        pl.prev[i] = (uint16_t)prev_slots[i]; pl.next[i] = (uint16_t)next_slots[i];
+    }
     return launch_pyrlk(ctx, pl, n_pairs, d_prev_xy, n_per_pair, d_next_xy, d_status, d_err, p);
 }
 
 extern "C" int ktlvo_pyrlk_dev(ktlvo_ctx *ctx, int prev_slot, int next_slot, const float *d_prev_xy, int n,
                                float *d_next_xy, uint8_t *d_status, float *d_err, const ktlvo_lk_params *p) {
     if (!ctx) return KTLVO_ERR_INVALID;
+    if (!slot_ok(ctx, prev_slot) || !slot_ok(ctx, next_slot)) return KTLVO_ERR_INVALID;
     PairList pl;
-    pl.prev[0] = prev_slot; pl.next[0] = next_slot;
+    pl.prev[0] = (uint16_t)prev_slot; pl.next[0] = (uint16_t)next_slot;
     return launch_pyrlk(ctx, pl, 1, d_prev_xy, n, d_next_xy, d_status, d_err, p);
 }
 

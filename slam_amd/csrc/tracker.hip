@@ -142,14 +142,14 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     KTLVO_HIP(ctx, hipMemcpyAsync(dA, featuresLastLeft.data(), (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
     { // circular check :457-479: LL->LR and LL->CL share their input list
         PairList pl;
-        pl.prev[0] = sLL; pl.next[0] = sLR;
-        pl.prev[1] = sLL; pl.next[1] = sCL;
+        pl.prev[0] = (uint16_t)sLL; pl.next[0] = (uint16_t)sLR;
+        pl.prev[1] = (uint16_t)sLL; pl.next[1] = (uint16_t)sCL;
         const int po[2] = {0, 0}, no[2] = {0, N};
         rc = launch_pyrlk_ex(ctx, pl, 2, dA, po, dBC, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
         if (rc != KTLVO_OK) return rc;
         // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft
-        pl.prev[0] = sLR; pl.next[0] = sCR;
-        pl.prev[1] = sCL; pl.next[1] = sCR;
+        pl.prev[0] = (uint16_t)sLR; pl.next[0] = (uint16_t)sCR;
+        pl.prev[1] = (uint16_t)sCL; pl.next[1] = (uint16_t)sCR;
         const int po2[2] = {0, N};
         rc = launch_pyrlk_ex(ctx, pl, 2, dBC, po2, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
         if (rc != KTLVO_OK) return rc;

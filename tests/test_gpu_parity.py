@@ -231,7 +231,7 @@ def test_lk_batch_equals_single_calls(make_ctx, klib):
         assert np.array_equal(e, de[i].cpu().numpy())
 
 
-@pytest.mark.parametrize("n_pairs,n", [(8, 5), (11, 333), (19, 64), (128, 9)])
+@pytest.mark.parametrize("n_pairs,n", [(8, 5), (11, 333), (19, 64), (256, 9)])
 def test_lk_batch_block_mapping(make_ctx, klib, n_pairs, n):
     """Pair counts around the kernel's grouping of pairs by 8 (full groups, groups plus left-over
     pairs, the launch capacity) and point counts that are not multiples of the 4 features of a
@@ -257,7 +257,7 @@ def test_lk_batch_block_mapping(make_ctx, klib, n_pairs, n):
     for i in range(n_pairs):
         o, st, e = ctx.pyrlk(prev[i], nxt[i], pts[i])
         assert np.array_equal(o, gn[i]) and np.array_equal(st, gs[i]) and np.array_equal(e, ge[i]), i
-    if n_pairs == 128:
+    if n_pairs == 256:
         with pytest.raises(klib.KtlvoError) as ei:
             ctx.pyrlk_batch_dev(prev + [0], nxt + [1], dp.data_ptr(), n, dn.data_ptr(), ds.data_ptr(), de.data_ptr(),
                                 klib.lk_params())
