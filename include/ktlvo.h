@@ -48,7 +48,7 @@ typedef struct {
     int max_level;                 /* featureTracking.cpp:81  lktPyramid = 4 (levels 0..4) */
     int win;                       /* featureTracking.cpp:80  winSize = 21 */
     int max_points;                /* capacity of one point list */
-    int max_batch_pairs;           /* capacity of ktlvo_pyrlk_batch_dev */
+    int max_batch_pairs;           /* capacity of ktlvo_pyrlk_batch_dev (default and upper limit 256) */
     int x_subregions, y_subregions;/* featureTracking.cpp:69-70 (20, 8) */
     int max_per_subregion;         /* featureTracking.cpp:68 (100) */
     int x_boundary, y_boundary;    /* featureTracking.cpp:74-75 (30, 30) */
