@@ -397,9 +397,12 @@ def main():
             "dtype": "u8 -> i32 fixed point, f32 sums",
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if rehearsal else ""),
             "config": {
-                "workload": "BASELINE configs[1]: %dx%d gray frame-pair stream, %d Shi-Tomasi corners/frame, "
-                            "maxLevel=%d (%d pyramid levels), 21x21 window, 30 it / eps 0.01" % (W, H, NF, a.max_level,
-                                                                                               levels),
+                "workload": "%s%dx%d gray frame-pair stream, %d Shi-Tomasi corners/frame, "
+                            "maxLevel=%d (%d pyramid levels), 21x21 window, 30 it / eps 0.01" % (
+                                "BASELINE configs[1]: " if (W, H, NF) == (1241, 376, 2000) else
+                                "BASELINE configs[2] shape: " if (W, H, NF) == (1920, 1080, 8000) else
+                                "BASELINE configs[4] shape: " if (W, H, NF) == (3840, 2160, 16384) else "",
+                                W, H, NF, a.max_level, levels),
                 "pairs_per_step": P,
                 "pipeline_contexts": len(ctxs),
                 "features_per_pair": NF,
