@@ -6,7 +6,6 @@ import os
 import sys
 from multiprocessing import Pool
 
-import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from slam_amd import shard, synth  # noqa: E402

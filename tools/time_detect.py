@@ -4,7 +4,6 @@
 import os
 import sys
 
-import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from slam_amd import lib as K, synth  # noqa: E402
