@@ -175,20 +175,21 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         rc = device_get_optical_flow(ctx, sLL, sCL, dT1, N, dCnt + 1, 5, dG2, dCHK, dK3, dCnt + 2, g);
         if (rc != KTLVO_OK) return rc;
     }
+    // One round trip for the whole frame: the three counts and the lists at their upper bound N (a few
+    // tens of kilobytes), trimmed on the host.
     int cnt[3];
+    std::vector<float> U1((size_t)N * 2), U2((size_t)N * 2), U3((size_t)N * 2);
+    std::vector<int> K1(N), K2(N), K3(N);
     KTLVO_HIP(ctx, hipMemcpyAsync(cnt, dCnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(U1.data(), dU1, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(U2.data(), dU2, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(U3.data(), dU3, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(K1.data(), dK1, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(K2.data(), dK2, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(K3.data(), dK3, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int n1 = cnt[0], n2 = cnt[1], n3 = cnt[2];
+    const int n3 = cnt[2];
     if (n3 == 0) return KTLVO_OK;
-    std::vector<float> U1((size_t)n3 * 2), U2((size_t)n3 * 2), U3((size_t)n3 * 2);
-    std::vector<int> K1(n1), K2(n2), K3(n3);
-    KTLVO_HIP(ctx, hipMemcpyAsync(U1.data(), dU1, (size_t)n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(U2.data(), dU2, (size_t)n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(U3.data(), dU3, (size_t)n3 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(K1.data(), dK1, (size_t)n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(K2.data(), dK2, (size_t)n2 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(K3.data(), dK3, (size_t)n3 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
     // :526-573 disparity -> depth and output assembly
     int nout = 0;
