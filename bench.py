@@ -139,7 +139,7 @@ def run_sequence(a, rank, world, local, dev):
                           "elapsed_s": r[5]} for r in recs.tolist()],
             "trajectory_shape": list(traj.shape),
             "note": "per frame: 2 host->device uploads (pinned staging), 1 pyramid + Scharr build for the two new "
-                    "images, 6 LK launches with device-side gating, RANSAC pose with one scoring launch"}))
+                    "images, 3 LK launches (the reference's 8 calls) with device-side gating, RANSAC pose with one scoring launch"}))
     ctx.close()
 
 

@@ -21,8 +21,8 @@ struct GateArgs {
     const int *d_n; // optional: n is read from device memory (capped by the n above)
     int *keep_idx;  // kept input indices, ascending
     int *n_keep;    // their number
-    const float *gsrc[3]; // optional point lists gathered through the kept indices ...
-    float *gdst[3];       // ... into these
+    const float *gsrc[MAX_GATHER]; // optional point lists gathered through the kept indices ...
+    float *gdst[MAX_GATHER];       // ... into these
 };
 
 __device__ __forceinline__ bool gate_keep(const GateArgs &a, int i) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(1024) void gate_compact(GateArgs a) {
             const int o = off + before;
             a.keep_idx[o] = i;
 #pragma unroll
-            for (int g = 0; g < 3; g++)
+            for (int g = 0; g < MAX_GATHER; g++)
                 if (a.gdst[g]) { a.gdst[g][2 * o] = a.gsrc[g][2 * i]; a.gdst[g][2 * o + 1] = a.gsrc[g][2 * i + 1]; }
         }
         __syncthreads();
@@ -84,7 +84,7 @@ int launch_fb_gate(ktlvo_ctx *ctx, const float *d_f1, const float *d_f2, const f
     a.max_track_dis = ctx->cfg.max_track_dis;
     a.y_threshold = (float)y_threshold;
     a.keep_idx = d_keep_idx; a.n_keep = d_n_keep;
-    for (int i = 0; i < 3; i++) { a.gsrc[i] = g.src[i]; a.gdst[i] = g.dst[i]; }
+    for (int i = 0; i < MAX_GATHER; i++) { a.gsrc[i] = g.src[i]; a.gdst[i] = g.dst[i]; }
     hipLaunchKernelGGL(gate_compact, dim3(1), dim3(1024), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
@@ -95,7 +95,7 @@ int launch_circular_gate(ktlvo_ctx *ctx, const float *d_pcr, const float *d_clr,
     GateArgs a = {};
     a.f1 = d_pcr; a.f2 = d_clr; a.f3 = nullptr; a.n = n; a.mode = 1; a.d_n = nullptr;
     a.keep_idx = d_keep_idx; a.n_keep = d_n_keep;
-    for (int i = 0; i < 3; i++) { a.gsrc[i] = g.src[i]; a.gdst[i] = g.dst[i]; }
+    for (int i = 0; i < MAX_GATHER; i++) { a.gsrc[i] = g.src[i]; a.gdst[i] = g.dst[i]; }
     hipLaunchKernelGGL(gate_compact, dim3(1), dim3(1024), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;

@@ -4,10 +4,11 @@
 
 namespace ktlvo {
 
-// Up to three point lists copied through the kept indices by a gate launch.
+// Up to four point lists copied through the kept indices by a gate launch.
+constexpr int MAX_GATHER = 4;
 struct Gather {
-    const float *src[3] = {nullptr, nullptr, nullptr};
-    float *dst[3] = {nullptr, nullptr, nullptr};
+    const float *src[MAX_GATHER] = {nullptr, nullptr, nullptr, nullptr};
+    float *dst[MAX_GATHER] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 int launch_fb_gate(ktlvo_ctx *ctx, const float *d_f1, const float *d_f2, const float *d_f1chk, int n, const int *d_n,

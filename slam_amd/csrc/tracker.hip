@@ -4,8 +4,8 @@
 //
 // Differences from the reference that do not change results: each image's pyramid is built once
 // and the cur -> last hand-over is a slot swap (the reference rebuilds 16 pyramids per frame for 4
-// distinct images); the 8 LK calls of a frame are enqueued as 6 launches with the gating and
-// compaction between them done on the device, so the host synchronises once per frame.
+// distinct images); the 8 LK calls of a frame become 3 launches (see the frame function) with the
+// gating and compaction between them done on the device, so the host synchronises once per frame.
 #include "ctx.hpp"
 #include "internal.hpp"
 
@@ -21,7 +21,8 @@ struct TrackerState {
     // device work lists (max_points points each)
     float *d_buf = nullptr;
     int *d_int = nullptr;
-    enum { A = 0, BC = 1 /* two lists */, DE = 3 /* two lists */, S1 = 5, F2, CHK, T1, T2, G2, U1, U2, U3, NLIST };
+    enum { A = 0, BC = 1 /* two lists */, DE = 3 /* two lists */, S1 = 5, F2, CHK /* two lists */, CHKB, T1, T2, G2, G3, CHK3,
+           U1, U2, U3, NLIST };
     float *list(int i, int cap) const { return d_buf + (size_t)i * cap * 2; }
 };
 
@@ -133,12 +134,18 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     typedef TrackerState TS;
     float *dA = t->list(TS::A, CAP), *dBC = t->list(TS::BC, CAP), *dDE = t->list(TS::DE, CAP);
     float *dS1 = t->list(TS::S1, CAP), *dF2 = t->list(TS::F2, CAP), *dCHK = t->list(TS::CHK, CAP);
-    float *dT1 = t->list(TS::T1, CAP), *dT2 = t->list(TS::T2, CAP), *dG2 = t->list(TS::G2, CAP);
+    float *dCHKB = t->list(TS::CHKB, CAP), *dT1 = t->list(TS::T1, CAP), *dT2 = t->list(TS::T2, CAP);
+    float *dG2 = t->list(TS::G2, CAP), *dG3 = t->list(TS::G3, CAP), *dCHK3 = t->list(TS::CHK3, CAP);
     float *dU1 = t->list(TS::U1, CAP), *dU2 = t->list(TS::U2, CAP), *dU3 = t->list(TS::U3, CAP);
     int *dK1 = t->d_int, *dK2 = t->d_int + CAP, *dK3 = t->d_int + 2 * CAP, *dCnt = t->d_int + 3 * CAP;
     const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4}; // :195-197, :208-209
     const int sLL = t->sLastL, sLR = t->sLastR, sCL = t->sCurL, sCR = t->sCurR;
 
+    // The reference makes 8 LK calls per frame.  A point's track depends on nothing but its two images
+    // and its start, so the two forward calls inside getOpticalFlow (:205) repeat, on a subset, what
+    // the circular check's first two calls (:457-467) computed: their results are carried through the
+    // gates instead, and the two backward calls (:214) of both getOpticalFlow stages share one launch
+    // over the points that passed the circular check.  Three launches, same values.
     KTLVO_HIP(ctx, hipMemcpyAsync(dA, featuresLastLeft.data(), (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
     { // circular check :457-479: LL->LR and LL->CL share their input list
         PairList pl;
@@ -154,25 +161,37 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         rc = launch_pyrlk_ex(ctx, pl, 2, dBC, po2, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
         if (rc != KTLVO_OK) return rc;
     }
-    { // :486-501
+    { // :486-501; the survivors' forward tracks LL->LR and LL->CL come along
         Gather g;
         g.src[0] = dA; g.dst[0] = dS1;
+        g.src[1] = dBC; g.dst[1] = dF2;                  // = calcOpticalFlowPyrLK(LastLeft, LastRight, selected) of :509
+        g.src[2] = dBC + 2 * (size_t)N; g.dst[2] = dG2;  // = calcOpticalFlowPyrLK(LastLeft, CurLeft, selected) of :513
         rc = launch_circular_gate(ctx, dDE, dDE + 2 * (size_t)N, N, dK1, dCnt + 0, g);
         if (rc != KTLVO_OK) return rc;
     }
-    { // getOpticalFlow(LastLeft, LastRight, selected, ..., y_threshold 1), :509
-        Gather g;
-        g.src[0] = dS1; g.dst[0] = dT1; // featuresLastLeftTemp
-        g.src[1] = dF2; g.dst[1] = dT2; // featuresLastRightTemp
-        rc = device_get_optical_flow(ctx, sLL, sLR, dS1, N, dCnt + 0, 1, dF2, dCHK, dK2, dCnt + 1, g);
+    { // backward tracks of both getOpticalFlow stages (:214): LR->LL from F2, CL->LL from G2
+        PairList pl;
+        pl.prev[0] = (uint16_t)sLR; pl.next[0] = (uint16_t)sLL;
+        pl.prev[1] = (uint16_t)sCL; pl.next[1] = (uint16_t)sLL;
+        const int po[2] = {0, (int)((dG2 - dF2) / 2)}, no[2] = {0, (int)((dCHKB - dCHK) / 2)};
+        rc = launch_pyrlk_ex(ctx, pl, 2, dF2, po, dCHK, no, ctx->d_status, ctx->d_err, N, dCnt + 0, &lk);
         if (rc != KTLVO_OK) return rc;
     }
-    { // getOpticalFlow(LastLeft, CurLeft, ..., y_threshold 5, temporal), :513
+    { // gate of getOpticalFlow(LastLeft, LastRight, ..., y_threshold 1), :509
+        Gather g;
+        g.src[0] = dS1; g.dst[0] = dT1;     // featuresLastLeftTemp
+        g.src[1] = dF2; g.dst[1] = dT2;     // featuresLastRightTemp
+        g.src[2] = dG2; g.dst[2] = dG3;     // their forward tracks into CurLeft ...
+        g.src[3] = dCHKB; g.dst[3] = dCHK3; // ... and back
+        rc = launch_fb_gate(ctx, dS1, dF2, dCHK, N, dCnt + 0, 1, dK2, dCnt + 1, g);
+        if (rc != KTLVO_OK) return rc;
+    }
+    { // gate of getOpticalFlow(LastLeft, CurLeft, ..., y_threshold 5, temporal), :513
         Gather g;
         g.src[0] = dT1; g.dst[0] = dU1; // featuresLastLeftSelect
-        g.src[1] = dG2; g.dst[1] = dU2; // featuresCurLeftSelect
+        g.src[1] = dG3; g.dst[1] = dU2; // featuresCurLeftSelect
         g.src[2] = dT2; g.dst[2] = dU3; // featuresLastRightSelect (features_depth)
-        rc = device_get_optical_flow(ctx, sLL, sCL, dT1, N, dCnt + 1, 5, dG2, dCHK, dK3, dCnt + 2, g);
+        rc = launch_fb_gate(ctx, dT1, dG3, dCHK3, N, dCnt + 1, 5, dK3, dCnt + 2, g);
         if (rc != KTLVO_OK) return rc;
     }
     // One round trip for the whole frame: the three counts and the lists at their upper bound N (a few
