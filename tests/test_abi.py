@@ -61,3 +61,32 @@ def test_create_fails_loudly_on_bad_config_or_missing_device(klib):
             pass
         else:
             raise AssertionError("Context() must raise without a GPU: there is no CPU fallback")
+
+
+def test_host_mirror_header_is_plain_cxx11_and_keeps_the_reference_names(tmp_path):
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "ktlvo_host.hpp")
+    tu = tmp_path / "tu.cpp"
+    tu.write_text('#include "ktlvo_host.hpp"\nint main() { return sizeof(ktlvo_host::Frontend) > 0 ? 0 : 1; }\n')
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I",
+                           os.path.join(ROOT, "include"), str(tu)])
+    txt = open(hdr).read()
+    for name in ("calcOpticalFlowPyrLK", "getOpticalFlow", "adaptiveNonMaximalSuppresion", "stereoImageCallback",
+                 "UnprojectStereo", "estimatePoseRANSAC", "pointCloudCallback"):
+        assert re.search(r"\b%s\s*\(" % name, txt), name
+    assert not re.search(r"#include\s*<(hip|opencv)", txt)
+
+
+def test_cxx_node_fails_loudly_without_a_device(tmp_path):
+    import subprocess
+    import torch
+    node = os.path.join(ROOT, "tests", "cpp", "frontend_node")
+    if not os.path.exists(node):
+        subprocess.check_call(["make", "-C", os.path.dirname(node)])
+    frames = tmp_path / "z.bin"
+    frames.write_bytes(bytes(64 * 48 * 2 * 2))
+    r = subprocess.run([node, "only-one-argument"], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([node, str(frames), "64", "48", "2", str(tmp_path / "o.bin")], capture_output=True, text=True)
+        assert r.returncode == 3 and "ktlvo_create failed" in r.stderr, r.stderr
