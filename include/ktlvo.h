@@ -14,6 +14,8 @@
  *     has been copied back;
  *   - a ktlvo_ctx is not thread-safe (the reference's callbacks are serialised by
  *     ros::spin(), featureTracking.cpp:727); use one context per GPU and host thread;
+ *   - a call makes its context's device the calling thread's current HIP device (and leaves it
+ *     so), so one thread may drive contexts on several GPUs in turn;
  *   - point lists are interleaved float (x,y) like std::vector<cv::Point2f>;
  *   - empty inputs (n == 0) are legal everywhere and return KTLVO_OK.
  */

@@ -389,6 +389,7 @@ using namespace ktlvo;
 extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *roi, int use_harris, double harris_k,
                                      float *out) {
     if (!ctx || !roi || !out || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (ctx->built[slot] < 0) return KTLVO_ERR_STATE;
     std::vector<RoiDev> rois;
     size_t total;
@@ -408,10 +409,12 @@ extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *
 extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois_in, int n_roi,
                                  const ktlvo_gftt_params *p, float *xy, float *response, int *counts, int cap) {
     if (!ctx || !p || n_roi < 0 || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (n_roi == 0) return KTLVO_OK;
     if (!rois_in || !xy || !response || !counts || cap <= 0) return KTLVO_ERR_INVALID;
     if (p->block_size != 3) return KTLVO_ERR_UNSUPPORTED;
     if (p->max_corners > cap) return KTLVO_ERR_INVALID;
+    if (!(p->quality > 0) || !(p->min_dist >= 0)) return KTLVO_ERR_INVALID; // goodFeaturesToTrack's own assertion
     if (ctx->built[slot] < 0) return KTLVO_ERR_STATE;
     std::vector<RoiDev> rois;
     size_t total;

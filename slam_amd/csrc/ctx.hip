@@ -183,6 +183,7 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
 
 extern "C" int ktlvo_set_stream(ktlvo_ctx *ctx, void *hip_stream) {
     if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return KTLVO_OK;
@@ -190,6 +191,7 @@ extern "C" int ktlvo_set_stream(ktlvo_ctx *ctx, void *hip_stream) {
 
 extern "C" int ktlvo_sync(ktlvo_ctx *ctx) {
     if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KTLVO_OK;
 }
@@ -211,6 +213,7 @@ extern "C" const char *ktlvo_last_error(const ktlvo_ctx *ctx) { return ctx ? ctx
 
 extern "C" int ktlvo_profile_enable(ktlvo_ctx *ctx, int on) {
     if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     ctx->prof.on = on != 0;
     return KTLVO_OK;
 }
@@ -235,6 +238,7 @@ static int profile_drain(ktlvo_ctx *ctx) {
 
 extern "C" int ktlvo_profile_reset(ktlvo_ctx *ctx) {
     if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     int rc = profile_drain(ctx);
     for (int k = 0; k < KTLVO_K_COUNT; k++) { ctx->prof.total_ms[k] = 0; ctx->prof.launches[k] = 0; }
     return rc;
@@ -242,6 +246,7 @@ extern "C" int ktlvo_profile_reset(ktlvo_ctx *ctx) {
 
 extern "C" int ktlvo_profile_get(ktlvo_ctx *ctx, int kid, double *total_ms, long long *launches) {
     if (!ctx || kid < 0 || kid >= KTLVO_K_COUNT) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     int rc = profile_drain(ctx);
     if (total_ms) *total_ms = ctx->prof.total_ms[kid];
     if (launches) *launches = ctx->prof.launches[kid];

@@ -100,6 +100,11 @@ int set_hip_error(ktlvo_ctx *ctx, hipError_t e, const char *what, const char *fi
         if (e_ != hipSuccess) return ktlvo::set_hip_error((ctx), e_, #call, __FILE__, __LINE__); \
     } while (0)
 
+// First statement of every entry point after its argument check: the context's device becomes the
+// calling thread's current device, so that lazy allocations and launches of a process that holds
+// contexts on several GPUs land on the right one.
+#define KTLVO_BIND(ctx) KTLVO_HIP((ctx), hipSetDevice((ctx)->device))
+
 // RAII bracket: records start/stop events around a launch when profiling is on.
 struct ProfScope {
     ktlvo_ctx *ctx;

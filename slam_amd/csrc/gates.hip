@@ -125,6 +125,7 @@ using namespace ktlvo;
 extern "C" int ktlvo_fb_gate(ktlvo_ctx *ctx, const float *f1, const float *f2, const float *f1_checked, int n,
                              int y_threshold, int *keep_idx, int *n_keep) {
     if (!ctx || n < 0 || !n_keep) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (n > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
     *n_keep = 0;
     if (n == 0) return KTLVO_OK;
@@ -147,6 +148,7 @@ extern "C" int ktlvo_fb_gate(ktlvo_ctx *ctx, const float *f1, const float *f2, c
 extern "C" int ktlvo_circular_gate(ktlvo_ctx *ctx, const float *pcr, const float *clr, int n, int *keep_idx,
                                    int *n_keep) {
     if (!ctx || n < 0 || !n_keep) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (n > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
     *n_keep = 0;
     if (n == 0) return KTLVO_OK;
@@ -189,6 +191,7 @@ int device_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float 
 extern "C" int ktlvo_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float *features_1, int n,
                                       int y_threshold, float *f1_sel, float *f2_sel, int *keep_idx, int *n_keep) {
     if (!ctx || n < 0 || !n_keep) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (n > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
     *n_keep = 0;
     if (n == 0) return KTLVO_OK;
@@ -216,10 +219,11 @@ extern "C" int ktlvo_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, co
 }
 
 extern "C" int ktlvo_anms(ktlvo_ctx *ctx, float *xy, float *response, int *n_inout, int num_to_keep) {
-    if (!ctx || !n_inout || *n_inout < 0) return KTLVO_ERR_INVALID;
+    if (!ctx || !n_inout || *n_inout < 0 || num_to_keep < 0) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     const int n = *n_inout;
     if (n > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
-    if (n < num_to_keep) return KTLVO_OK; // featureTracking.cpp:261
+    if (n < num_to_keep || n == 0) return KTLVO_OK; // featureTracking.cpp:261
     if (!xy || !response) return KTLVO_ERR_INVALID;
     struct KP { float x, y, response; };
     std::vector<KP> kp(n);

@@ -201,17 +201,15 @@ using namespace ktlvo;
 // the caller's buffer has been read.
 extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride) {
     if (!ctx || !img || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w) return KTLVO_ERR_INVALID;
     const size_t bytes = (size_t)w * h;
     StageRing &r = ctx->stage;
-    if (!r.h_buf[0]) {
-        for (int i = 0; i < StageRing::N; i++) {
-            KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_buf[i], bytes, hipHostMallocDefault));
-            KTLVO_HIP(ctx, hipMalloc((void **)&r.d_buf[i], bytes));
-            KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming));
-        }
-    }
     const int k = r.next;
+    // each ring entry is made on its first use; a failure leaves it partly made and the next call retries
+    if (!r.h_buf[k]) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_buf[k], bytes, hipHostMallocDefault));
+    if (!r.d_buf[k]) KTLVO_HIP(ctx, hipMalloc((void **)&r.d_buf[k], bytes));
+    if (!r.done[k]) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
     r.next = (r.next + 1) % StageRing::N;
     if (r.used[k]) KTLVO_HIP(ctx, hipEventSynchronize(r.done[k])); // that buffer's previous DMA and ingest are over
     if (stride == w) {
@@ -229,12 +227,14 @@ extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, 
 
 extern "C" int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride) {
     if (!ctx || !d_img || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w) return KTLVO_ERR_INVALID;
     return launch_ingest(ctx, slot, d_img, stride);
 }
 
 extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slots, int max_level, int win) {
     if (!ctx || n_slots < 0 || (n_slots > 0 && !slots) || max_level < 0) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (win != ctx->cfg.win) return KTLVO_ERR_UNSUPPORTED; // level count and frame were sized for cfg.win
     const int top = max_level < ctx->n_levels - 1 ? max_level : ctx->n_levels - 1;
     for (int i = 0; i < n_slots; i++) {
@@ -271,12 +271,14 @@ extern "C" int ktlvo_build_pyramid(ktlvo_ctx *ctx, int slot, int max_level, int 
 
 extern "C" int ktlvo_pyramid_levels(ktlvo_ctx *ctx, int slot, int *max_level_built) {
     if (!ctx || !slot_ok(ctx, slot) || !max_level_built) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     *max_level_built = ctx->built[slot];
     return KTLVO_OK;
 }
 
 extern "C" int ktlvo_download_level(ktlvo_ctx *ctx, int slot, int level, uint8_t *dst, int *w, int *h) {
     if (!ctx || !slot_ok(ctx, slot) || !dst || level < 0) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (level > ctx->built[slot]) return KTLVO_ERR_STATE;
     const LevelDesc &L = ctx->h_slots[slot].lv[level];
     KTLVO_HIP(ctx, hipMemcpy2DAsync(dst, L.w, L.origin, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
@@ -288,6 +290,7 @@ extern "C" int ktlvo_download_level(ktlvo_ctx *ctx, int slot, int level, uint8_t
 
 extern "C" int ktlvo_download_scharr(ktlvo_ctx *ctx, int slot, int level, int16_t *dst) {
     if (!ctx || !slot_ok(ctx, slot) || !dst || level < 0) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (level > ctx->built[slot] || !ctx->deriv_ok[slot]) return KTLVO_ERR_STATE;
     const LevelDesc &L = ctx->h_slots[slot].lv[level];
     KTLVO_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)L.w * 4, L.dorigin, (size_t)L.pitch * 4, (size_t)L.w * 4, L.h,

@@ -562,7 +562,8 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
                     const int *d_n, const ktlvo_lk_params *p) {
     if (!p) return KTLVO_ERR_INVALID;
     if (p->win != WIN) return KTLVO_ERR_UNSUPPORTED;
-    if (n_pairs <= 0 || n_pairs > MAX_BATCH || n_per_pair < 0) return KTLVO_ERR_INVALID;
+    if (n_pairs <= 0 || n_pairs > MAX_BATCH || n_per_pair < 0 || p->max_level < 0) return KTLVO_ERR_INVALID;
+    if ((long long)n_pairs * n_per_pair > 0x7fffffffLL) return KTLVO_ERR_CAPACITY; // point indices are 32-bit
     if (n_per_pair == 0) return KTLVO_OK;
     if (!d_prev || !d_next || !d_status || !d_err) return KTLVO_ERR_INVALID;
     int max_level = p->max_level;
@@ -618,6 +619,7 @@ extern "C" int ktlvo_pyrlk_batch_dev(ktlvo_ctx *ctx, const int *prev_slots, cons
                                      const float *d_prev_xy, int n_per_pair, float *d_next_xy, uint8_t *d_status,
                                      float *d_err, const ktlvo_lk_params *p) {
     if (!ctx || !prev_slots || !next_slots || n_pairs < 0) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (n_pairs > ctx->cfg.max_batch_pairs) return KTLVO_ERR_CAPACITY;
     if (n_pairs == 0) return KTLVO_OK;
     PairList pl;
@@ -631,6 +633,7 @@ extern "C" int ktlvo_pyrlk_batch_dev(ktlvo_ctx *ctx, const int *prev_slots, cons
 extern "C" int ktlvo_pyrlk_dev(ktlvo_ctx *ctx, int prev_slot, int next_slot, const float *d_prev_xy, int n,
                                float *d_next_xy, uint8_t *d_status, float *d_err, const ktlvo_lk_params *p) {
     if (!ctx) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (!slot_ok(ctx, prev_slot) || !slot_ok(ctx, next_slot)) return KTLVO_ERR_INVALID;
     PairList pl;
     pl.prev[0] = (uint16_t)prev_slot; pl.next[0] = (uint16_t)next_slot;
@@ -640,6 +643,7 @@ extern "C" int ktlvo_pyrlk_dev(ktlvo_ctx *ctx, int prev_slot, int next_slot, con
 extern "C" int ktlvo_pyrlk(ktlvo_ctx *ctx, int prev_slot, int next_slot, const float *prev_xy, int n, float *next_xy,
                            uint8_t *status, float *err, const ktlvo_lk_params *p) {
     if (!ctx || n < 0) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (n > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
     if (n == 0) {
         if (!p) return KTLVO_ERR_INVALID;

@@ -143,6 +143,7 @@ using namespace ktlvo;
 extern "C" int ktlvo_ransac_score(ktlvo_ctx *ctx, const float *X3, const float *x2, int n, const double *Rt, int H,
                                   const double K[4], float thr_sq, int *counts, int mask_hyp, uint8_t *best_mask) {
     if (!ctx || n < 0 || H < 0 || !K) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     if (H > ctx->cfg.max_hypotheses || n > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
     if (H == 0) return KTLVO_OK;
     if (!counts || !Rt || (n > 0 && (!X3 || !x2))) return KTLVO_ERR_INVALID;
@@ -169,6 +170,7 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
                                       float reproj_err, double confidence, double rvec[3], double tvec[3],
                                       uint8_t *inlier_mask, int *n_inliers, int *found) {
     if (!ctx || n < 0 || !found || !rvec || !tvec) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     *found = 0;
     if (n_inliers) *n_inliers = 0;
     const int modelPoints = 4;

@@ -60,6 +60,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
                                         ktlvo_depth_point *last, ktlvo_image_point *cur, int cap, int *n_out,
                                         int *new_key_frame) {
     if (!ctx || !left || !right || !n_out || cap < 0 || (cap > 0 && (!last || !cur))) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     *n_out = 0;
     if (new_key_frame) *new_key_frame = 0;
     TrackerState *t;
@@ -235,6 +236,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
 extern "C" int ktlvo_estimate_pose(ktlvo_ctx *ctx, const ktlvo_depth_point *last, const ktlvo_image_point *cur, int n,
                                    float T_local[16], float T_global[16], int *n_inliers) {
     if (!ctx || n < 0 || !T_local || !T_global || (n > 0 && (!last || !cur))) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
     TrackerState *t;
     int rc = tracker_get(ctx, &t);
     if (rc != KTLVO_OK) return rc;

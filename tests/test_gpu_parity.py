@@ -122,6 +122,31 @@ def test_lk_golden_and_edge_cases(make_ctx, klib):
     assert ei.value.status == klib.ERR_CAPACITY
 
 
+def test_argument_checks_mirror_opencv_assertions(make_ctx, klib):
+    ctx = make_ctx(width=160, height=120)
+    img = synth.texture_image(160, 120, seed=5, noise=True)
+    ctx.upload_image(0, img)
+    ctx.upload_image(1, img)
+    ctx.build_pyramids([0, 1])
+    pts = np.array([[80.0, 60.0]], np.float32)
+    for bad in (klib.lk_params(max_level=-1),):
+        with pytest.raises(klib.KtlvoError) as ei:
+            ctx.pyrlk(0, 1, pts, bad)
+        assert ei.value.status == klib.ERR_INVALID
+    for bad in (klib.gftt_params(quality=0.0), klib.gftt_params(min_dist=-1.0)):
+        with pytest.raises(klib.KtlvoError) as ei:
+            ctx.detect_gftt(0, [(0, 0, 64, 64)], bad)
+        assert ei.value.status == klib.ERR_INVALID
+    with pytest.raises(klib.KtlvoError) as ei:
+        ctx.anms(np.zeros((4, 2), np.float32), np.zeros(4, np.float32), -1)
+    assert ei.value.status == klib.ERR_INVALID
+    xy, resp = ctx.anms(np.zeros((0, 2), np.float32), np.zeros(0, np.float32), 0)   # nothing in, nothing out
+    assert len(xy) == 0 and len(resp) == 0
+    # the context still works after refused calls
+    o, s, e = ctx.pyrlk(0, 1, pts)
+    assert s[0] == 1 and np.abs(o - pts).max() < 1e-3
+
+
 def test_lk_max_level_3_and_iteration_limits(make_ctx, oracle, klib):
     a, b = synth.texture_pair(640, 480, 8, 4.2, 2.1)
     ctx = make_ctx(width=640, height=480)
