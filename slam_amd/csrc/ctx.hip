@@ -50,6 +50,20 @@ int ensure_misc(ktlvo_ctx *ctx, size_t bytes) {
     return KTLVO_OK;
 }
 
+int ensure_pin(ktlvo_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->pin_bytes) return KTLVO_OK;
+    if (ctx->h_pin) {
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KTLVO_HIP(ctx, hipHostFree(ctx->h_pin));
+        ctx->h_pin = nullptr;
+        ctx->pin_bytes = 0;
+    }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    KTLVO_HIP(ctx, hipHostMalloc(&ctx->h_pin, bytes, hipHostMallocDefault));
+    ctx->pin_bytes = bytes;
+    return KTLVO_OK;
+}
+
 int effective_max_level(const ktlvo_ctx *ctx, int a, int b, int requested) {
     int m = requested;
     if (ctx->built[a] < m) m = ctx->built[a];
@@ -175,6 +189,7 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
     if (ctx->d_misc) (void)hipFree(ctx->d_misc);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

@@ -84,6 +84,8 @@ struct ktlvo_ctx {
     int *d_idx = nullptr;   // max_points + 1 ints
     void *d_misc = nullptr; // corner / ransac work area
     size_t misc_bytes = 0;
+    void *h_pin = nullptr;  // pinned host mirror of (part of) the work area: one DMA instead of one per array
+    size_t pin_bytes = 0;
 
     ktlvo::StageRing stage;
     ktlvo::Profiler prof;
@@ -115,6 +117,7 @@ struct ProfScope {
 };
 
 int ensure_misc(ktlvo_ctx *ctx, size_t bytes);
+int ensure_pin(ktlvo_ctx *ctx, size_t bytes);
 inline bool slot_ok(const ktlvo_ctx *ctx, int s) { return s >= 0 && s < ctx->cfg.num_slots; }
 int effective_max_level(const ktlvo_ctx *ctx, int a, int b, int requested);
 

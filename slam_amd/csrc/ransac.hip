@@ -110,6 +110,9 @@ struct ScoreBuffers {
     double *d_Rt, *d_rv;
     unsigned char *d_valid, *d_mask;
     int *d_counts, *d_idx;
+    // X3, x2, Rt and valid are adjacent at the head of the work area (offsets o_x, o_Rt, o_valid,
+    // up_bytes in all), so a pinned host image of that head goes up in one copy
+    size_t o_x, o_Rt, o_valid, up_bytes;
 };
 
 static int carve_score(ktlvo_ctx *ctx, int n, int H, ScoreBuffers &b) {
@@ -124,6 +127,7 @@ static int carve_score(ktlvo_ctx *ctx, int n, int H, ScoreBuffers &b) {
     b.d_X3 = (float *)(p + o_X); b.d_x2 = (float *)(p + o_x); b.d_Rt = (double *)(p + o_Rt);
     b.d_valid = (unsigned char *)(p + o_valid); b.d_mask = (unsigned char *)(p + o_mask); b.d_counts = (int *)(p + o_cnt);
     b.d_rv = (double *)(p + o_rv); b.d_idx = (int *)(p + o_idx);
+    b.o_x = o_x; b.o_Rt = o_Rt; b.o_valid = o_valid; b.up_bytes = o_valid + up(H);
     return KTLVO_OK;
 }
 
@@ -200,20 +204,30 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
     }
     // 2. minimal solver per hypothesis; the model is kept as (rvec, tvec) and R is rebuilt from
     //    rvec for scoring, as PnPRansacCallback does.  3. one launch scores every hypothesis.
-    std::vector<double> Rt((size_t)12 * H, 0.0), rv((size_t)3 * H, 0.0);
-    std::vector<unsigned char> valid(H, 0);
-    std::vector<int> counts(H);
+    std::vector<double> rv((size_t)3 * H, 0.0), Rt_dev;
+    std::vector<unsigned char> valid_dev;
     ScoreBuffers b;
     int rc = carve_score(ctx, n, H, b);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(b.d_X3, X3, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(b.d_x2, x2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = ensure_pin(ctx, b.up_bytes + (size_t)H * 4);
+    if (rc != KTLVO_OK) return rc;
+    char *hp = (char *)ctx->h_pin;
+    const int *counts = (const int *)(hp + b.up_bytes);
+    const double *Rt;
+    const unsigned char *valid;
+    memcpy(hp, X3, (size_t)n * 12);
+    memcpy(hp + b.o_x, x2, (size_t)n * 8);
     if (ctx->cfg.device_p3p) {
+        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_X3, hp, b.o_x + (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
         KTLVO_HIP(ctx, hipMemcpyAsync(b.d_idx, idx.data(), (size_t)H * 16, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ransac_p3p, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, b.d_X3, b.d_x2, b.d_idx, H, K[0],
                            K[1], K[2], K[3], b.d_Rt, b.d_rv, b.d_valid);
         KTLVO_HIP(ctx, hipGetLastError());
     } else {
+        double *Rt_h = (double *)(hp + b.o_Rt);
+        unsigned char *valid_h = (unsigned char *)(hp + b.o_valid);
+        memset(Rt_h, 0, (size_t)H * 96);
+        memset(valid_h, 0, H);
         for (int it = 0; it < H; it++) {
             double Xs[12], us[8];
             for (int i = 0; i < 4; i++) {
@@ -223,21 +237,28 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
             }
             p3p::Pose P;
             if (!p3p::solve4(Xs, us, K, P)) continue;
-            valid[it] = 1;
+            valid_h[it] = 1;
             p3p::rodrigues_m2v(P.R, &rv[3 * (size_t)it]);
-            p3p::rodrigues_v2m(&rv[3 * (size_t)it], &Rt[12 * (size_t)it]);
-            memcpy(&Rt[12 * (size_t)it + 9], P.t, 3 * sizeof(double));
+            p3p::rodrigues_v2m(&rv[3 * (size_t)it], &Rt_h[12 * (size_t)it]);
+            memcpy(&Rt_h[12 * (size_t)it + 9], P.t, 3 * sizeof(double));
         }
-        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_Rt, Rt.data(), (size_t)H * 96, hipMemcpyHostToDevice, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_valid, valid.data(), H, hipMemcpyHostToDevice, ctx->stream));
+        // points, poses and flags in one copy from the pinned image of the work area's head
+        KTLVO_HIP(ctx, hipMemcpyAsync(b.d_X3, hp, b.o_valid + (size_t)H, hipMemcpyHostToDevice, ctx->stream));
     }
     rc = launch_score(ctx, b, n, H, b.d_valid, K, thr_sq, -1, false);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(counts.data(), b.d_counts, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(hp + b.up_bytes, b.d_counts, (size_t)H * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->cfg.device_p3p) {
-        KTLVO_HIP(ctx, hipMemcpyAsync(valid.data(), b.d_valid, H, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(Rt.data(), b.d_Rt, (size_t)H * 96, hipMemcpyDeviceToHost, ctx->stream));
+        Rt_dev.resize((size_t)12 * H);
+        valid_dev.resize(H);
+        KTLVO_HIP(ctx, hipMemcpyAsync(valid_dev.data(), b.d_valid, H, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(Rt_dev.data(), b.d_Rt, (size_t)H * 96, hipMemcpyDeviceToHost, ctx->stream));
         KTLVO_HIP(ctx, hipMemcpyAsync(rv.data(), b.d_rv, (size_t)H * 24, hipMemcpyDeviceToHost, ctx->stream));
+        Rt = Rt_dev.data();
+        valid = valid_dev.data();
+    } else {
+        Rt = (const double *)(hp + b.o_Rt);
+        valid = (const unsigned char *)(hp + b.o_valid);
     }
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // 4. replay of the sequential acceptance rule

@@ -20,16 +20,22 @@ struct TrackerState {
     float mTcw[16], mTcwLocal[16];                      // visualOdometry.cpp:113-114
     // device work lists (max_points points each)
     float *d_buf = nullptr;
-    int *d_int = nullptr;
+    // What the host reads back each frame, contiguous so that one copy fetches it: 8 counters, then for
+    // the frame's N start points the three gates' kept-index lists (N ints each) and the three final
+    // point lists (2N floats each).  h_io is its pinned host image; the start points go up through it too.
+    int *d_out = nullptr;
+    int *h_io = nullptr;
     enum { A = 0, BC = 1 /* two lists */, DE = 3 /* two lists */, S1 = 5, F2, CHK /* two lists */, CHKB, T1, T2, G2, G3, CHK3,
-           U1, U2, U3, NLIST };
+           NLIST };
+    static size_t out_ints(size_t n) { return 8 + 9 * n; }
     float *list(int i, int cap) const { return d_buf + (size_t)i * cap * 2; }
 };
 
 void tracker_free(ktlvo_ctx *ctx) {
     if (!ctx->tracker) return;
     if (ctx->tracker->d_buf) (void)hipFree(ctx->tracker->d_buf);
-    if (ctx->tracker->d_int) (void)hipFree(ctx->tracker->d_int);
+    if (ctx->tracker->d_out) (void)hipFree(ctx->tracker->d_out);
+    if (ctx->tracker->h_io) (void)hipHostFree(ctx->tracker->h_io);
     delete ctx->tracker;
     ctx->tracker = nullptr;
 }
@@ -40,13 +46,13 @@ static int tracker_get(ktlvo_ctx *ctx, TrackerState **out) {
         TrackerState *t = new TrackerState;
         for (int i = 0; i < 16; i++) t->mTcw[i] = t->mTcwLocal[i] = (i % 5 == 0) ? 1.f : 0.f;
         const size_t cap = ctx->cfg.max_points;
+        ctx->tracker = t;
         if (hipMalloc((void **)&t->d_buf, (size_t)TrackerState::NLIST * cap * 8) != hipSuccess ||
-            hipMalloc((void **)&t->d_int, (3 * cap + 8) * sizeof(int)) != hipSuccess) {
-            if (t->d_buf) (void)hipFree(t->d_buf);
-            delete t;
+            hipMalloc((void **)&t->d_out, TrackerState::out_ints(cap) * sizeof(int)) != hipSuccess ||
+            hipHostMalloc((void **)&t->h_io, TrackerState::out_ints(cap) * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            tracker_free(ctx);
             return KTLVO_ERR_NOMEM;
         }
-        ctx->tracker = t;
     }
     *out = ctx->tracker;
     return KTLVO_OK;
@@ -137,8 +143,8 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     float *dS1 = t->list(TS::S1, CAP), *dF2 = t->list(TS::F2, CAP), *dCHK = t->list(TS::CHK, CAP);
     float *dCHKB = t->list(TS::CHKB, CAP), *dT1 = t->list(TS::T1, CAP), *dT2 = t->list(TS::T2, CAP);
     float *dG2 = t->list(TS::G2, CAP), *dG3 = t->list(TS::G3, CAP), *dCHK3 = t->list(TS::CHK3, CAP);
-    float *dU1 = t->list(TS::U1, CAP), *dU2 = t->list(TS::U2, CAP), *dU3 = t->list(TS::U3, CAP);
-    int *dK1 = t->d_int, *dK2 = t->d_int + CAP, *dK3 = t->d_int + 2 * CAP, *dCnt = t->d_int + 3 * CAP;
+    int *dCnt = t->d_out, *dK1 = dCnt + 8, *dK2 = dK1 + N, *dK3 = dK2 + N;
+    float *dU1 = (float *)(dK3 + N), *dU2 = dU1 + 2 * (size_t)N, *dU3 = dU2 + 2 * (size_t)N;
     const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4}; // :195-197, :208-209
     const int sLL = t->sLastL, sLR = t->sLastR, sCL = t->sCurL, sCR = t->sCurR;
 
@@ -147,7 +153,8 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     // the circular check's first two calls (:457-467) computed: their results are carried through the
     // gates instead, and the two backward calls (:214) of both getOpticalFlow stages share one launch
     // over the points that passed the circular check.  Three launches, same values.
-    KTLVO_HIP(ctx, hipMemcpyAsync(dA, featuresLastLeft.data(), (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+    memcpy(t->h_io, featuresLastLeft.data(), (size_t)N * 8); // the previous frame's read of h_io ended with its sync
+    KTLVO_HIP(ctx, hipMemcpyAsync(dA, t->h_io, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
     { // circular check :457-479: LL->LR and LL->CL share their input list
         PairList pl;
         pl.prev[0] = (uint16_t)sLL; pl.next[0] = (uint16_t)sLR;
@@ -195,19 +202,11 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         rc = launch_fb_gate(ctx, dT1, dG3, dCHK3, N, dCnt + 1, 5, dK3, dCnt + 2, g);
         if (rc != KTLVO_OK) return rc;
     }
-    // One round trip for the whole frame: the three counts and the lists at their upper bound N (a few
-    // tens of kilobytes), trimmed on the host.
-    int cnt[3];
-    std::vector<float> U1((size_t)N * 2), U2((size_t)N * 2), U3((size_t)N * 2);
-    std::vector<int> K1(N), K2(N), K3(N);
-    KTLVO_HIP(ctx, hipMemcpyAsync(cnt, dCnt, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(U1.data(), dU1, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(U2.data(), dU2, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(U3.data(), dU3, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(K1.data(), dK1, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(K2.data(), dK2, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(K3.data(), dK3, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // One copy and one synchronisation for the whole frame (36 N + 32 bytes into pinned memory).
+    KTLVO_HIP(ctx, hipMemcpyAsync(t->h_io, t->d_out, TS::out_ints(N) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int *cnt = t->h_io, *K1 = cnt + 8, *K2 = K1 + N, *K3 = K2 + N;
+    const float *U1 = (const float *)(K3 + N), *U2 = U1 + 2 * (size_t)N, *U3 = U2 + 2 * (size_t)N;
     const int n3 = cnt[2];
     if (n3 == 0) return KTLVO_OK;
 

@@ -215,7 +215,7 @@ class Context:
             raise RuntimeError("ktlvo_create failed (no MI355X visible, bad config or out of memory)")
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # lib is None while the interpreter shuts down
             lib.ktlvo_destroy(self._h)
             self._h = None
 
