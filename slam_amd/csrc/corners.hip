@@ -13,6 +13,8 @@
 #include "ctx.hpp"
 #include "internal.hpp"
 
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 
@@ -328,6 +330,8 @@ struct CornerWork {
     unsigned long long *d_cand;
     float *d_xy, *d_oresp;
     int *d_counts;
+    // the results (xy, responses, counts, overflow flag) are adjacent: out_bytes from d_xy on
+    size_t off_oresp, off_counts, off_overflow, out_bytes;
 };
 
 static int carve(ktlvo_ctx *ctx, int n_roi, size_t total_px, int cap, CornerWork &w) {
@@ -336,18 +340,20 @@ static int carve(ktlvo_ctx *ctx, int n_roi, size_t total_px, int cap, CornerWork
     size_t o_resp = o_rois + up(sizeof(RoiDev) * n_roi);
     size_t o_max = o_resp + up(total_px * 4);
     size_t o_cnt = o_max + up(4 * (size_t)n_roi);
-    size_t o_ovf = o_cnt + up(4 * (size_t)n_roi);
-    size_t o_cand = o_ovf + 256;
+    size_t o_cand = o_cnt + up(4 * (size_t)n_roi);
     size_t o_xy = o_cand + up(total_px * 8);
     size_t o_or = o_xy + up((size_t)n_roi * cap * 8);
     size_t o_counts = o_or + up((size_t)n_roi * cap * 4);
-    size_t total = o_counts + up(4 * (size_t)n_roi);
+    size_t o_ovf = o_counts + up(4 * (size_t)n_roi);
+    size_t total = o_ovf + 256;
     int rc = ensure_misc(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_misc;
     w.d_rois = (RoiDev *)(b + o_rois); w.d_resp = (float *)(b + o_resp); w.d_max = (unsigned *)(b + o_max);
     w.d_cnt = (int *)(b + o_cnt); w.d_overflow = (int *)(b + o_ovf); w.d_cand = (unsigned long long *)(b + o_cand);
     w.d_xy = (float *)(b + o_xy); w.d_oresp = (float *)(b + o_or); w.d_counts = (int *)(b + o_counts);
+    w.off_oresp = o_or - o_xy; w.off_counts = o_counts - o_xy; w.off_overflow = o_ovf - o_xy;
+    w.out_bytes = o_ovf + 4 - o_xy;
     return KTLVO_OK;
 }
 
@@ -448,12 +454,16 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
         a.min_dist = p->min_dist; a.xy = w.d_xy; a.resp = w.d_oresp; a.counts = w.d_counts; a.overflow = w.d_overflow;
         hipLaunchKernelGGL(corner_select, dim3(n_roi), dim3(256), 0, ctx->stream, a);
         KTLVO_HIP(ctx, hipGetLastError());
-        int ovf = 0;
-        KTLVO_HIP(ctx, hipMemcpyAsync(counts, w.d_counts, 4 * (size_t)n_roi, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(&ovf, w.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(xy, w.d_xy, (size_t)n_roi * cap * 8, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(response, w.d_oresp, (size_t)n_roi * cap * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // one copy home through pinned memory, then into the caller's three arrays
+        rc = ensure_pin(ctx, w.out_bytes);
+        if (rc != KTLVO_OK) return rc;
+        const char *hp = (const char *)ctx->h_pin;
+        KTLVO_HIP(ctx, hipMemcpyAsync(ctx->h_pin, w.d_xy, w.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(xy, hp, (size_t)n_roi * cap * 8);
+        memcpy(response, hp + w.off_oresp, (size_t)n_roi * cap * 4);
+        memcpy(counts, hp + w.off_counts, 4 * (size_t)n_roi);
+        const int ovf = *(const int *)(hp + w.off_overflow);
         if (ovf) { ctx->last_error = "corner_select: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
         return KTLVO_OK;
     }

@@ -52,12 +52,17 @@ int ensure_misc(ktlvo_ctx *ctx, size_t bytes) {
 
 int ensure_pin(ktlvo_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->pin_bytes) return KTLVO_OK;
+    const size_t old_bytes = ctx->pin_bytes;
     if (ctx->h_pin) {
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         KTLVO_HIP(ctx, hipHostFree(ctx->h_pin));
         ctx->h_pin = nullptr;
         ctx->pin_bytes = 0;
     }
+    // at least 256 KiB and at least twice the old size: a sequence of slowly growing requests must
+    // not turn into a sequence of reallocations
+    if (bytes < 2 * old_bytes) bytes = 2 * old_bytes;
+    if (bytes < ((size_t)256 << 10)) bytes = (size_t)256 << 10;
     bytes = (bytes + 4095) & ~(size_t)4095;
     KTLVO_HIP(ctx, hipHostMalloc(&ctx->h_pin, bytes, hipHostMallocDefault));
     ctx->pin_bytes = bytes;

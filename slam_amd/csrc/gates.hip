@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstring>
 #include <limits>
 
 namespace ktlvo {
@@ -122,6 +123,15 @@ __global__ __launch_bounds__(256) void anms_radius(const float *xy, const float 
 
 using namespace ktlvo;
 
+// Work area and pinned mirror for a host-pointer gate call: `lists` input lists of n points, then 8
+// counters (the first is the kept count) and n kept indices.
+static int host_gate_io(ktlvo_ctx *ctx, int n, int lists) {
+    const size_t bytes = (size_t)lists * n * 8 + (8 + (size_t)n) * sizeof(int);
+    int rc = ensure_misc(ctx, bytes);
+    if (rc != KTLVO_OK) return rc;
+    return ensure_pin(ctx, bytes);
+}
+
 extern "C" int ktlvo_fb_gate(ktlvo_ctx *ctx, const float *f1, const float *f2, const float *f1_checked, int n,
                              int y_threshold, int *keep_idx, int *n_keep) {
     if (!ctx || n < 0 || !n_keep) return KTLVO_ERR_INVALID;
@@ -130,18 +140,21 @@ extern "C" int ktlvo_fb_gate(ktlvo_ctx *ctx, const float *f1, const float *f2, c
     *n_keep = 0;
     if (n == 0) return KTLVO_OK;
     if (!f1 || !f2 || !f1_checked || !keep_idx) return KTLVO_ERR_INVALID;
+    // three lists up in one copy, count and kept indices down in one copy, both through pinned memory
     const size_t b = (size_t)n * 8;
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[0], f1, b, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[1], f2, b, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[2], f1_checked, b, hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_fb_gate(ctx, ctx->d_pts[0], ctx->d_pts[1], ctx->d_pts[2], n, nullptr, y_threshold, ctx->d_idx,
-                            ctx->d_idx + ctx->cfg.max_points, Gather());
+    int rc = host_gate_io(ctx, n, 3);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(n_keep, ctx->d_idx + ctx->cfg.max_points, sizeof(int), hipMemcpyDeviceToHost,
-                                  ctx->stream));
+    char *hp = (char *)ctx->h_pin;
+    memcpy(hp, f1, b); memcpy(hp + b, f2, b); memcpy(hp + 2 * b, f1_checked, b);
+    float *d_in = (float *)ctx->d_misc;
+    int *d_cnt = (int *)(d_in + 6 * (size_t)n), *d_keep = d_cnt + 8;
+    KTLVO_HIP(ctx, hipMemcpyAsync(d_in, hp, 3 * b, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_fb_gate(ctx, d_in, d_in + 2 * (size_t)n, d_in + 4 * (size_t)n, n, nullptr, y_threshold, d_keep, d_cnt, Gather());
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemcpyAsync(hp, d_cnt, (8 + (size_t)n) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (*n_keep > 0)
-        KTLVO_HIP(ctx, hipMemcpy(keep_idx, ctx->d_idx, (size_t)*n_keep * sizeof(int), hipMemcpyDeviceToHost));
+    *n_keep = ((const int *)hp)[0];
+    memcpy(keep_idx, hp + 8 * sizeof(int), (size_t)*n_keep * sizeof(int));
     return KTLVO_OK;
 }
 
@@ -154,16 +167,19 @@ extern "C" int ktlvo_circular_gate(ktlvo_ctx *ctx, const float *pcr, const float
     if (n == 0) return KTLVO_OK;
     if (!pcr || !clr || !keep_idx) return KTLVO_ERR_INVALID;
     const size_t b = (size_t)n * 8;
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[0], pcr, b, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[1], clr, b, hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_circular_gate(ctx, ctx->d_pts[0], ctx->d_pts[1], n, ctx->d_idx, ctx->d_idx + ctx->cfg.max_points,
-                                  Gather());
+    int rc = host_gate_io(ctx, n, 2);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(n_keep, ctx->d_idx + ctx->cfg.max_points, sizeof(int), hipMemcpyDeviceToHost,
-                                  ctx->stream));
+    char *hp = (char *)ctx->h_pin;
+    memcpy(hp, pcr, b); memcpy(hp + b, clr, b);
+    float *d_in = (float *)ctx->d_misc;
+    int *d_cnt = (int *)(d_in + 4 * (size_t)n), *d_keep = d_cnt + 8;
+    KTLVO_HIP(ctx, hipMemcpyAsync(d_in, hp, 2 * b, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_circular_gate(ctx, d_in, d_in + 2 * (size_t)n, n, d_keep, d_cnt, Gather());
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemcpyAsync(hp, d_cnt, (8 + (size_t)n) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (*n_keep > 0)
-        KTLVO_HIP(ctx, hipMemcpy(keep_idx, ctx->d_idx, (size_t)*n_keep * sizeof(int), hipMemcpyDeviceToHost));
+    *n_keep = ((const int *)hp)[0];
+    memcpy(keep_idx, hp + 8 * sizeof(int), (size_t)*n_keep * sizeof(int));
     return KTLVO_OK;
 }
 
@@ -196,25 +212,31 @@ extern "C" int ktlvo_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, co
     *n_keep = 0;
     if (n == 0) return KTLVO_OK;
     if (!features_1 || !f1_sel || !f2_sel || !keep_idx) return KTLVO_ERR_INVALID;
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[0], features_1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = ensure_misc(ctx, (size_t)n * 8 * 2);
+    // outputs back to back in the work area: 8 counters, n kept indices, the two gathered lists;
+    // one copy up and one copy down through pinned memory
+    const size_t out_bytes = (8 + (size_t)n) * sizeof(int) + (size_t)n * 16;
+    int rc = ensure_misc(ctx, out_bytes);
     if (rc != KTLVO_OK) return rc;
-    float *d_s1 = (float *)ctx->d_misc, *d_s2 = d_s1 + 2 * (size_t)n;
-    int *d_cnt = ctx->d_idx + ctx->cfg.max_points;
+    rc = ensure_pin(ctx, out_bytes);
+    if (rc != KTLVO_OK) return rc;
+    char *hp = (char *)ctx->h_pin;
+    int *d_cnt = (int *)ctx->d_misc, *d_keep = d_cnt + 8;
+    float *d_s1 = (float *)(d_keep + n), *d_s2 = d_s1 + 2 * (size_t)n;
+    memcpy(hp, features_1, (size_t)n * 8);
+    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[0], hp, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     Gather g;
     g.src[0] = ctx->d_pts[0]; g.dst[0] = d_s1;
     g.src[1] = ctx->d_pts[2]; g.dst[1] = d_s2;
     rc = device_get_optical_flow(ctx, slot_1, slot_2, ctx->d_pts[0], n, nullptr, y_threshold, ctx->d_pts[2],
-                                 ctx->d_pts[3], ctx->d_idx, d_cnt, g);
+                                 ctx->d_pts[3], d_keep, d_cnt, g);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(n_keep, d_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(hp, ctx->d_misc, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int m = *n_keep;
-    if (m > 0) {
-        KTLVO_HIP(ctx, hipMemcpy(f1_sel, d_s1, (size_t)m * 8, hipMemcpyDeviceToHost));
-        KTLVO_HIP(ctx, hipMemcpy(f2_sel, d_s2, (size_t)m * 8, hipMemcpyDeviceToHost));
-        KTLVO_HIP(ctx, hipMemcpy(keep_idx, ctx->d_idx, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
-    }
+    const int m = *n_keep = ((const int *)hp)[0];
+    const char *h_keep = hp + 8 * sizeof(int), *h_s1 = h_keep + (size_t)n * sizeof(int), *h_s2 = h_s1 + (size_t)n * 8;
+    memcpy(keep_idx, h_keep, (size_t)m * sizeof(int));
+    memcpy(f1_sel, h_s1, (size_t)m * 8);
+    memcpy(f2_sel, h_s2, (size_t)m * 8);
     return KTLVO_OK;
 }
 

@@ -18,6 +18,8 @@
 // int16 patch values, 2^-20 scale); only the accumulation order of the float sums differs.
 #include "ctx.hpp"
 
+#include <cstring>
+
 namespace ktlvo {
 
 struct LkArgs {
@@ -650,12 +652,25 @@ extern "C" int ktlvo_pyrlk(ktlvo_ctx *ctx, int prev_slot, int next_slot, const f
         return p->win == WIN ? KTLVO_OK : KTLVO_ERR_UNSUPPORTED;
     }
     if (!prev_xy || !next_xy || !status || !err) return KTLVO_ERR_INVALID;
-    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[0], prev_xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    int rc = ktlvo_pyrlk_dev(ctx, prev_slot, next_slot, ctx->d_pts[0], n, ctx->d_pts[1], ctx->d_status, ctx->d_err, p);
+    // Results land back to back (positions, errors, status bytes) in the work area, so that they come
+    // home in one copy through pinned memory; a copy per array into pageable memory costs more than
+    // the kernel for a frame's worth of points.
+    const size_t res_bytes = (size_t)n * 13;
+    int rc = ensure_misc(ctx, res_bytes);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(next_xy, ctx->d_pts[1], (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(status, ctx->d_status, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    KTLVO_HIP(ctx, hipMemcpyAsync(err, ctx->d_err, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    rc = ensure_pin(ctx, res_bytes);
+    if (rc != KTLVO_OK) return rc;
+    char *hp = (char *)ctx->h_pin;
+    float *d_next = (float *)ctx->d_misc, *d_err = d_next + 2 * (size_t)n;
+    uint8_t *d_status = (uint8_t *)(d_err + n);
+    memcpy(hp, prev_xy, (size_t)n * 8);
+    KTLVO_HIP(ctx, hipMemcpyAsync(ctx->d_pts[0], hp, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = ktlvo_pyrlk_dev(ctx, prev_slot, next_slot, ctx->d_pts[0], n, d_next, d_status, d_err, p);
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemcpyAsync(hp, ctx->d_misc, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(next_xy, hp, (size_t)n * 8);
+    memcpy(err, hp + (size_t)n * 8, (size_t)n * 4);
+    memcpy(status, hp + (size_t)n * 12, (size_t)n);
     return KTLVO_OK;
 }

@@ -17,6 +17,7 @@
 
 #include "../../oracle/ktlvo_oracle.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -212,15 +213,27 @@ int main(int argc, char **argv) {
         std::vector<orc_image_point> oCur(cfg.max_points);
 
         std::ofstream out(argv[5], std::ios::binary);
-        int keyFrames = 0;
+        int keyFrames = 0, nKey = 0, nPlain = 0;
+        double msA = 0, msB = 0, msKeyA = 0, msKeyB = 0;
         long tracked = 0;
         double worst = 0;
         for (int f = 0; f < NF; f++) {
             const uint8_t *L = &frames[(size_t)W * H * 2 * f], *R = L + (size_t)W * H;
             std::vector<DepthPoint> lastA, lastB;
             std::vector<ImagePoint> curA, curB;
+            const auto t0 = std::chrono::steady_clock::now();
             const bool keyA = node.stereoImageCallback(L, R, W, H, lastA, curA);
+            const auto t1 = std::chrono::steady_clock::now();
             const bool keyB = feB.stereoImageCallback(L, R, lastB, curB);
+            const auto t2 = std::chrono::steady_clock::now();
+            if (std::getenv("KTLVO_NODE_VERBOSE"))
+                std::fprintf(stderr, "frame %d key %d: call by call %.3f ms, one call %.3f ms\n", f, (int)keyA,
+                             std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+            if (f > 2) { // the first calls allocate
+                (keyA ? msKeyA : msA) += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                (keyA ? msKeyB : msB) += std::chrono::duration<double, std::milli>(t2 - t1).count();
+                (keyA ? nKey : nPlain) += 1;
+            }
             EXPECT(keyA == keyB, "frame %d", f);
             EXPECT(lastA.size() == lastB.size() && curA.size() == curB.size(), "frame %d: %zu vs %zu", f, lastA.size(), lastB.size());
             if (lastA.size() == lastB.size() && !lastA.empty()) {
@@ -263,6 +276,8 @@ int main(int argc, char **argv) {
         if (otr) orc_tracker_destroy(otr);
         EXPECT(keyFrames >= 1, "no key frame in %d frames", NF);
         EXPECT(worst <= 0.25, "worst node-vs-oracle deviation %g px", worst);
+        if (nPlain) std::printf("per frame, call by call %.3f ms, one call %.3f ms (%d frames)\n", msA / nPlain, msB / nPlain, nPlain);
+        if (nKey) std::printf("per key frame, call by call %.3f ms, one call %.3f ms (%d frames)\n", msKeyA / nKey, msKeyB / nKey, nKey);
         std::printf("frontend_node: %d frames, %d key frames, %ld tracked points, worst |node - oracle| = %.5f px, %d failures\n", NF,
                     keyFrames, tracked, worst, g_failures);
     } catch (const Error &e) {

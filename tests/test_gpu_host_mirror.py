@@ -29,6 +29,7 @@ def test_reference_shaped_node_matches_frame_path_and_oracle(tmp_path, make_ctx,
     r = subprocess.run([NODE, str(raw), str(W), str(H), str(NF), str(outp)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 failures" in r.stdout, r.stdout
+    print(r.stdout)
 
     # the node's output against the ctypes path of this process
     blob = np.fromfile(outp, np.uint8)
