@@ -256,6 +256,39 @@ def test_lk_batch_equals_single_calls(make_ctx, klib):
         assert np.array_equal(e, de[i].cpu().numpy())
 
 
+def test_caller_stream_and_device_buffers(make_ctx, klib):
+    """ktlvo_set_stream + the *_dev entry points: frames and point lists that already live in HBM, work
+    enqueued on the caller's stream without any synchronisation inside the library."""
+    import torch
+    W, H = 640, 360
+    a, b = synth.texture_pair(W, H, 31, 1.7, -2.2, noise=True)
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    ctx.build_pyramids([0, 1])
+    rng = np.random.default_rng(3)
+    pts = np.stack([rng.uniform(20, W - 20, 700), rng.uniform(20, H - 20, 700)], 1).astype(np.float32)
+    ref = ctx.pyrlk(0, 1, pts)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        da, db = torch.from_numpy(a).cuda(non_blocking=True), torch.from_numpy(b).cuda(non_blocking=True)
+        dp = torch.from_numpy(pts).cuda(non_blocking=True)
+        dn = torch.zeros_like(dp)
+        ds = torch.zeros(len(pts), dtype=torch.uint8, device="cuda")
+        de = torch.zeros(len(pts), dtype=torch.float32, device="cuda")
+        ctx.set_image_dev(2, da.data_ptr(), W, H, W)
+        ctx.set_image_dev(3, db.data_ptr(), W, H, W)
+        ctx.build_pyramids([2, 3])
+        ctx.pyrlk_dev(2, 3, dp.data_ptr(), len(pts), dn.data_ptr(), ds.data_ptr(), de.data_ptr(), klib.lk_params())
+    stream.synchronize()
+    assert np.array_equal(dn.cpu().numpy(), ref[0]) and np.array_equal(ds.cpu().numpy(), ref[1])
+    assert np.array_equal(de.cpu().numpy(), ref[2])
+    ctx.set_stream(None)     # back to the context's own stream
+    again = ctx.pyrlk(2, 3, pts)
+    assert np.array_equal(again[0], ref[0])
+
+
 @pytest.mark.parametrize("n_pairs,n", [(8, 5), (11, 333), (19, 64), (256, 9)])
 def test_lk_batch_block_mapping(make_ctx, klib, n_pairs, n):
     """Pair counts around the kernel's grouping of pairs by 8 (full groups, groups plus left-over

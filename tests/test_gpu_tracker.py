@@ -13,7 +13,7 @@ def _ate(traj, gt):
 
 
 def test_tracker_matches_oracle_on_corridor(make_ctx, oracle):
-    W, H, NF = 1242, 375, 12
+    W, H, NF = 1242, 375, 16   # long enough for a second key frame (tracked count falls below 300)
     scene = synth.CorridorScene(W, H, seed=0x5EED0001)
     ctx = make_ctx()
     ocfg = oracle.default_config(nthreads=8)
@@ -48,7 +48,7 @@ def test_tracker_matches_oracle_on_corridor(make_ctx, oracle):
         o_traj.append(oTg[:3, 3].copy())
         Tgt = Tgt @ scene.relative_pose(f - 1, f)
         gt.append(Tgt[:3, 3].copy())
-    assert kf_seen >= 1
+    assert kf_seen >= 2
     g_traj, o_traj, gt = np.array(g_traj), np.array(o_traj), np.array(gt)
     ate_g, ate_o = _ate(g_traj, gt), _ate(o_traj, gt)
     path = np.abs(gt[-1]).max()
@@ -67,3 +67,22 @@ def test_tracker_edge_cases(make_ctx, klib):
     assert len(last) == 0 and kf
     n, Tl, Tg = ctx.estimate_pose(last, cur)                # empty input: pose stays identity
     assert n == -1 and np.array_equal(Tl, np.eye(4, dtype=np.float32)) and np.array_equal(Tg, Tl)
+
+
+def test_tracker_output_capacity(make_ctx, klib):
+    """Arrays too small for a frame's points: the call says so, fills what fits, and the tracker's own
+    state stays whole (the next frame goes on as if nothing had happened)."""
+    W, H = 1242, 375
+    scene = synth.CorridorScene(W, H, seed=0x5EED0001)
+    a, b = make_ctx(), make_ctx()
+    for f in range(4):
+        L, R = scene.stereo_pair(f)
+        ref = a.track_stereo_frame(L, R)
+        if f == 2:
+            with pytest.raises(klib.KtlvoError) as ei:
+                b.track_stereo_frame(L, R, cap=10)
+            assert ei.value.status == klib.ERR_CAPACITY
+        else:
+            got = b.track_stereo_frame(L, R)
+            assert len(got[0]) == len(ref[0]) and got[0].tobytes() == ref[0].tobytes()
+            assert got[1].tobytes() == ref[1].tobytes() and got[2] == ref[2]
