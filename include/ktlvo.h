@@ -107,7 +107,10 @@ const char *ktlvo_strerror(int status);
 const char *ktlvo_last_error(const ktlvo_ctx *ctx); /* text of the last HIP failure */
 
 /* ---- images and pyramids ---------------------------------------------------------------- */
-/* cv_bridge::toCvCopy(msg, MONO8) -> Mat (featureTracking.cpp:346-365): host image into a slot. */
+/* cv_bridge::toCvCopy(msg, MONO8) -> Mat (featureTracking.cpp:346-365): host image into a slot.
+ * Pageable memory is copied before the call returns.  Pinned memory (hipHostMalloc, hipHostRegister)
+ * is read by DMA after the call returns: leave it unchanged until a call that waits for the device
+ * (ktlvo_sync, or any host-pointer call that returns results, ktlvo_track_stereo_frame included). */
 int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride);
 /* Same from a device buffer (frame already resident in HBM). */
 int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride);

@@ -205,6 +205,27 @@ extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, 
     if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w) return KTLVO_ERR_INVALID;
     const size_t bytes = (size_t)w * h;
     StageRing &r = ctx->stage;
+    // A frame that already sits in pinned host memory (hipHostMalloc / hipHostRegister) is read by the
+    // DMA engine where it lies; the staging copy below is for pageable memory only.
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, img) == hipSuccess && attr.type == hipMemoryTypeHost) {
+        const int k = r.next;
+        r.next = (r.next + 1) % StageRing::N;
+        if (!r.d_buf[k]) KTLVO_HIP(ctx, hipMalloc((void **)&r.d_buf[k], bytes));
+        if (!r.done[k]) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
+        if (r.used[k]) KTLVO_HIP(ctx, hipEventSynchronize(r.done[k]));
+        if (stride == w)
+            KTLVO_HIP(ctx, hipMemcpyAsync(r.d_buf[k], img, bytes, hipMemcpyHostToDevice, ctx->stream));
+        else
+            KTLVO_HIP(ctx, hipMemcpy2DAsync(r.d_buf[k], (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h,
+                                            hipMemcpyHostToDevice, ctx->stream));
+        int rc = launch_ingest(ctx, slot, r.d_buf[k], w);
+        if (rc != KTLVO_OK) return rc;
+        KTLVO_HIP(ctx, hipEventRecord(r.done[k], ctx->stream));
+        r.used[k] = true;
+        return KTLVO_OK;
+    }
+    (void)hipGetLastError(); // an unregistered pointer is reported as an error by some runtimes
     const int k = r.next;
     // each ring entry is made on its first use; a failure leaves it partly made and the next call retries
     if (!r.h_buf[k]) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_buf[k], bytes, hipHostMallocDefault));

@@ -245,9 +245,12 @@ class Context:
 
     # -- images
     def upload_image(self, slot, img):
-        img = np.ascontiguousarray(img, np.uint8)
+        """img: uint8 (h, w); rows may be padded (a view with strides (stride, 1)), as in a cv::Mat with step > cols."""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
-        self._chk(lib.ktlvo_upload_image(self._h, slot, _ptr(img), w, h, w), "ktlvo_upload_image")
+        self._chk(lib.ktlvo_upload_image(self._h, slot, _ptr(img), w, h, img.strides[0]), "ktlvo_upload_image")
 
     def set_image_dev(self, slot, dptr, w, h, stride):
         self._chk(lib.ktlvo_set_image_dev(self._h, slot, dptr, w, h, stride), "ktlvo_set_image_dev")

@@ -62,6 +62,29 @@ def test_pyramid_kat_and_golden(make_ctx):
         assert np.array_equal(ctx.download_scharr(0, l, lv.shape[1], lv.shape[0]), g["scharr%d" % l])
 
 
+def test_upload_from_padded_and_pinned_rows(make_ctx):
+    """The three ways a frame can arrive (packed pageable, padded rows, pinned memory read by DMA in
+    place, padded or not) give the same planes."""
+    import torch
+    W, H = 333, 77
+    img = synth.texture_image(W, H, seed=9, noise=True)
+    ctx = make_ctx(width=W, height=H, num_slots=5)
+    padded = np.zeros((H, W + 59), np.uint8)
+    padded[:, :W] = img
+    pin_packed = torch.from_numpy(img.copy()).pin_memory()
+    pin_padded = torch.from_numpy(padded.copy()).pin_memory()
+    ctx.upload_image(0, img)
+    ctx.upload_image(1, padded[:, :W])
+    ctx.upload_image(2, pin_packed.numpy())
+    ctx.upload_image(3, pin_padded.numpy()[:, :W])
+    ctx.build_pyramids([0, 1, 2, 3])
+    for l in range(ctx.pyramid_levels(0) + 1):
+        ref = ctx.download_level(0, l)
+        for s in (1, 2, 3):
+            assert np.array_equal(ctx.download_level(s, l), ref), (s, l)
+    assert np.array_equal(ctx.download_level(0, 0), img)
+
+
 def test_pyramid_batched_build_equals_single(make_ctx):
     ctx = make_ctx(width=320, height=240, num_slots=6)
     imgs = [synth.texture_image(320, 240, seed=s) for s in range(6)]

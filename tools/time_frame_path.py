@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Wall-clock split of the per-frame calls (ktlvo_track_stereo_frame / ktlvo_estimate_pose) on a
-synthetic stereo corridor; run on a GPU box.  usage: time_frame_path.py [frames] [device_p3p]"""
+synthetic stereo corridor; run on a GPU box.  usage: time_frame_path.py [frames] [device_p3p] [pinned]
+(pinned = 1: the frames are handed over in pinned host memory, which the library reads by DMA directly)"""
 import os
 import sys
 import time
@@ -15,6 +16,11 @@ dp3p = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 W, H = 1242, 375
 scene = synth.CorridorScene(W, H, seed=0x5EED0010)
 frames = [scene.stereo_pair(f) for f in range(n)]
+if len(sys.argv) > 3 and int(sys.argv[3]):
+    import torch
+    keep = [(torch.from_numpy(np.ascontiguousarray(L)).pin_memory(), torch.from_numpy(np.ascontiguousarray(R)).pin_memory())
+            for L, R in frames]
+    frames = [(L.numpy(), R.numpy()) for L, R in keep]
 ctx = K.Context(K.default_config(width=W, height=H, device_p3p=dp3p))
 tt, tp, kfs, npts = [], [], [], []
 for f, (L, R) in enumerate(frames):
