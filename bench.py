@@ -265,11 +265,19 @@ def main():
                            cx=scene.cx, cy=scene.cy)
     ctxs = [K.Context(cfg, device=local) for _ in range(max(1, a.pipeline))]
     ctx = ctxs[0]
-    t_h2d = time.perf_counter()
-    for s, f in enumerate(frames):
-        ctx.upload_image(s, f)
-    ctx.sync()
-    t_h2d = time.perf_counter() - t_h2d
+    def upload_all(src):
+        t = time.perf_counter()
+        for s, f in enumerate(src):
+            ctx.upload_image(s, f)
+        ctx.sync()
+        return time.perf_counter() - t
+
+    upload_all(frames)                       # first pass allocates the staging ring
+    t_h2d = min(upload_all(frames) for _ in range(3))   # frames in pageable memory: staged through the pinned ring
+    pinned = [torch.from_numpy(np.ascontiguousarray(f)).pin_memory() for f in frames] if rank == 0 else []
+    src = [t.numpy() for t in pinned]
+    t_h2d_pinned = min(upload_all(src) for _ in range(3)) if pinned else None   # read by DMA in place
+    del pinned, src
     for c in ctxs[1:]:
         for s, f in enumerate(frames):
             c.upload_image(s, f)
@@ -442,6 +450,8 @@ def main():
                 "pyrlk_track_w21": {"avg_ms_per_step": k3_ms / max(k3_n, 1)},
             },
             "h2d_inclusive": {"value": total_tracked / world / (t_max / a.steps + t_h2d),
+                              "value_pinned_source": total_tracked / world / (t_max / a.steps + t_h2d_pinned),
+                              "upload_ms": {"pageable_source": t_h2d * 1e3, "pinned_source": t_h2d_pinned * 1e3},
                               "note": "rank-0 rate if the %d frames of a step were uploaded from host memory "
                                       "(pinned staging ring) every step (%.1f ms); never the headline value" % (P + 1, t_h2d * 1e3)},
             "per_rank": [{"features_in": r[0], "tracked": r[1], "k3_ms": r[3], "k1_ms": r[5], "elapsed_s": r[7]}
