@@ -86,3 +86,31 @@ def test_tracker_output_capacity(make_ctx, klib):
             got = b.track_stereo_frame(L, R)
             assert len(got[0]) == len(ref[0]) and got[0].tobytes() == ref[0].tobytes()
             assert got[1].tobytes() == ref[1].tobytes() and got[2] == ref[2]
+
+
+def test_contexts_on_concurrent_host_threads(make_ctx):
+    """Different contexts are independent: three host threads, each driving its own context over the
+    same frames at the same time, get the very same clouds and poses."""
+    import threading
+    W, H, NF = 1242, 375, 6
+    scene = synth.CorridorScene(W, H, seed=0x5EED0001)
+    frames = [scene.stereo_pair(f) for f in range(NF)]
+    ctxs = [make_ctx() for _ in range(3)]
+    out = [None] * len(ctxs)
+
+    def drive(i):
+        res = []
+        for L, R in frames:
+            last, cur, kf = ctxs[i].track_stereo_frame(L, R)
+            _, Tl, Tg = ctxs[i].estimate_pose(last, cur)
+            res.append((last.tobytes(), cur.tobytes(), kf, Tl.tobytes(), Tg.tobytes()))
+        out[i] = res
+
+    threads = [threading.Thread(target=drive, args=(i,)) for i in range(len(ctxs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(o is not None for o in out)
+    assert out[1] == out[0] and out[2] == out[0]
+    assert len(out[0][-1][0]) > 100 * 24
