@@ -175,8 +175,8 @@ def run_sequence(a, rank, world, local, dev):
 
 
 def run_ransac(a, rank, world, local, dev):
-    """K9 alone: 1024 pose hypotheses x 8000 points (BASELINE configs[2]), inputs resident in HBM is not
-    offered by the C ABI for this call, so the rate includes the 160 KB + 98 KB host-to-device copies."""
+    """K9 alone: 1024 pose hypotheses x 8000 points (BASELINE configs[2]), through the host-pointer call
+    (copies included) and through the device-pointer call with every array resident in HBM."""
     rng = np.random.default_rng(3 + rank)
     Kc = np.array([1093.5, 1093.5, 960.0, 540.0])
     n, Hh = 8000, 1024
@@ -187,74 +187,53 @@ def run_ransac(a, rank, world, local, dev):
     ctx = K.Context(K.default_config(width=1920, height=1080, fx=Kc[0], fy=Kc[1], cx=Kc[2], cy=Kc[3]), device=local)
     for _ in range(a.warmup):
         ctx.ransac_score(X, uv, Rt, Kc, np.float32(4.0))
-    ctx.profile_enable(True)
-    ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         counts = ctx.ransac_score(X, uv, Rt, Kc, np.float32(4.0))
     elapsed = time.perf_counter() - t0
-    ms, nl = ctx.profile_get(K.K_RANSAC)
-    if rank == 0:
+    # the same with every array resident in HBM (ktlvo_ransac_score_dev), at the reference's 0.1 px
+    # threshold (thr^2 = 0.01) and at the looser 2 px one (thr^2 = 4)
+    dX, dx = torch.from_numpy(X).to(dev), torch.from_numpy(uv).to(dev)
+    dRt = torch.from_numpy(Rt).to(dev)
+    dcnt = torch.zeros(Hh, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    algo = 20.0 * n * Hh + 100.0 * Hh
+    resident = {}
+    for thr in (0.01, 4.0):
+        for _ in range(a.warmup):
+            ctx.ransac_score_dev(dX.data_ptr(), dx.data_ptr(), n, dRt.data_ptr(), Hh, Kc, thr, dcnt.data_ptr())
+        ctx.sync()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            ctx.ransac_score_dev(dX.data_ptr(), dx.data_ptr(), n, dRt.data_ptr(), Hh, Kc, thr, dcnt.data_ptr())
+        ctx.sync()
+        wall = (time.perf_counter() - t1) / a.steps
+        ms, nl = ctx.profile_get(K.K_RANSAC)
+        ctx.profile_enable(False)
         k_s = ms / max(nl, 1) * 1e-3
-        algo = 20.0 * n * Hh + 100.0 * Hh
+        dev_counts = dcnt.cpu().numpy()
+        if thr == 4.0:
+            assert np.array_equal(dev_counts, counts), "device-pointer and host-pointer scoring disagree"
+        resident["thr_sq_%g" % thr] = {
+            "scores_per_s": n * Hh / wall, "ms_per_call": wall * 1e3, "kernel_ms": k_s * 1e3,
+            "kernel_scores_per_s": n * Hh / k_s if k_s > 0 else None,
+            "kernel_GBps": algo / k_s / 1e9 if k_s > 0 else None, "max_count": int(dev_counts.max())}
+    if rank == 0:
+        r4 = resident["thr_sq_4"]
         print(json.dumps({
             "metric": "RANSAC hypothesis x point scores/sec (1024 hypotheses x 8000 points)",
-            "value": n * Hh * a.steps / elapsed, "unit": "scores/s (host-pointer call, copies included)",
-            "kernel_only_scores_per_s": n * Hh / k_s if k_s > 0 else None, "kernel_ms": k_s * 1e3,
-            "roofline": {"bound": "hbm", "kernel": "ransac_score", "achieved": algo / k_s / 1e9 if k_s > 0 else None,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / k_s / 1e9 / HBM_PEAK_GBS if k_s > 0 else None,
+            "value": r4["scores_per_s"], "unit": "scores/s (arrays resident in HBM, thr^2 = 4)",
+            "resident": resident,
+            "host_pointer_call": {"scores_per_s": n * Hh * a.steps / elapsed,
+                                  "note": "ktlvo_ransac_score: 160 KB + 98 KB host-to-device and 4 KB back per call"},
+            "roofline": {"bound": "hbm", "kernel": "ransac_score", "achieved": r4["kernel_GBps"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": r4["kernel_GBps"] / HBM_PEAK_GBS if r4["kernel_GBps"] else None,
                          "algorithmic_bytes": algo},
             "max_count": int(counts.max()), "n_gpus": world, "data": "synthetic"}))
     ctx.close()
-
-
-def cpu_baseline(frames, pts, max_level, budget_s):
-    """The oracle (a port of the OpenCV path the reference calls) timed on the host cores: per
-    pair both pyramids, the previous image's Scharr planes and the LK loop, as one
-    cv::calcOpticalFlowPyrLK call does.  Bounded sample: the first pairs of the same workload,
-    repeated until the time budget is spent."""
-    import oracle as O
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
-    n_pairs = min(len(frames) - 1, 4)
-
-    def timed(threads, budget):
-        tracked, t0, reps = 0, time.perf_counter(), 0
-        while True:
-            for i in range(n_pairs):
-                pa = O.Pyramid(frames[i], max_level, WIN, True)
-                pb = O.Pyramid(frames[i + 1], max_level, WIN, False)
-                _, st, _ = O.pyrlk(pa, pb, pts[i], WIN, max_level, nthreads=threads)
-                tracked += int(st.sum())
-            reps += 1
-            el = time.perf_counter() - t0
-            if el >= budget or reps >= 1000:
-                return tracked / el, reps, el
-
-    v_all, reps, el = timed(cores, budget_s)
-    v_one, reps1, el1 = timed(1, max(1.0, budget_s * 0.3))
-    # Gauss-Newton steps per level of the first pair (levels listed from level 0 up)
-    it, _ = O.lk_iterations(O.Pyramid(frames[0], max_level, WIN, True), O.Pyramid(frames[1], max_level, WIN, False),
-                            pts[0], max_level=max_level)
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": v_all, "unit": "tracked features/s", "cores": cores, "kind": "port",
-            "sample": "first %d frame pairs x %d features of the same workload, %d repetitions, %.1f s; "
-                      "pyramids + Scharr + LK per pair (one calcOpticalFlowPyrLK each), points range-split "
-                      "over %d threads" % (n_pairs, pts.shape[1], reps, el, cores),
-            "single_thread": {"value": v_one, "cores": 1, "sample": "%d repetitions, %.1f s" % (reps1, el1)},
-            "cpu_model": model,
-            "lk_iterations_per_level_mean": [float(x) for x in it.mean(1)],
-            "lk_iterations_per_feature_mean": float(it.sum(0).mean())}
 
 
 def main():

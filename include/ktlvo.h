@@ -177,6 +177,11 @@ int ktlvo_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float *
 int ktlvo_ransac_score(ktlvo_ctx *ctx, const float *X3, const float *x2, int n, const double *Rt,
                        int H, const double K[4], float thr_sq, int *counts, int mask_hyp,
                        uint8_t *best_mask);
+/* The same on device-resident arrays, enqueued on the context's stream without synchronising; no
+ * capacity limits apply (the caller owns every buffer: d_counts H ints, d_mask n bytes or NULL). */
+int ktlvo_ransac_score_dev(ktlvo_ctx *ctx, const float *d_X3, const float *d_x2, int n,
+                           const double *d_Rt, int H, const double K[4], float thr_sq, int *d_counts,
+                           int mask_hyp, uint8_t *d_mask);
 /* cv::solvePnPRansac(P3d, p2d, K, 0, rvec, tvec, false, iters, reproj, conf, inliers, P3P)
  * as called by estimatePoseRANSAC (visualOdometry.cpp:177-217): hypotheses are drawn with
  * cv::RNG((uint64)-1), solved by P3P, scored in one batch on the GPU, and OpenCV's sequential

@@ -170,6 +170,24 @@ extern "C" int ktlvo_ransac_score(ktlvo_ctx *ctx, const float *X3, const float *
     return KTLVO_OK;
 }
 
+extern "C" int ktlvo_ransac_score_dev(ktlvo_ctx *ctx, const float *d_X3, const float *d_x2, int n, const double *d_Rt, int H,
+                                      const double K[4], float thr_sq, int *d_counts, int mask_hyp, uint8_t *d_mask) {
+    if (!ctx || n < 0 || H < 0 || !K) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (H == 0) return KTLVO_OK;
+    if (!d_counts || !d_Rt || (n > 0 && (!d_X3 || !d_x2))) return KTLVO_ERR_INVALID;
+    if (d_mask && (mask_hyp < 0 || mask_hyp >= H)) return KTLVO_ERR_INVALID;
+    if (n == 0) {
+        KTLVO_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int) * (size_t)H, ctx->stream));
+        return KTLVO_OK;
+    }
+    ProfScope ps(ctx, KTLVO_K_RANSAC);
+    hipLaunchKernelGGL(ransac_score, dim3(H), dim3(256), 0, ctx->stream, d_X3, d_x2, n, d_Rt, (const unsigned char *)nullptr,
+                       K[0], K[1], K[2], K[3], thr_sq, d_counts, mask_hyp, d_mask);
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
 extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const float *x2, int n, int max_iters,
                                       float reproj_err, double confidence, double rvec[3], double tvec[3],
                                       uint8_t *inlier_mask, int *n_inliers, int *found) {

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ktlvo_circular_gate": (_i, [_vp, _vp, _vp, _i, _vp, _ip]),
     "ktlvo_get_optical_flow": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _ip]),
     "ktlvo_ransac_score": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp]),
+    "ktlvo_ransac_score_dev": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _f, _vp, _i, _vp]),
     "ktlvo_solve_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _i, _f, _d, _vp, _vp, _vp, _ip, _ip]),
     "ktlvo_track_stereo_frame": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ip, _ip]),
     "ktlvo_estimate_pose": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _ip]),
@@ -377,6 +378,12 @@ class Context:
         self._chk(lib.ktlvo_ransac_score(self._h, _ptr(X3), _ptr(x2), n, _ptr(Rt), H, _ptr(K), np.float32(thr_sq),
                                          _ptr(counts), mask_hyp, _ptr(mask)), "ktlvo_ransac_score")
         return (counts[:H], mask[:n]) if mask is not None else counts[:H]
+
+    def ransac_score_dev(self, d_X3, d_x2, n, d_Rt, H, K, thr_sq, d_counts, mask_hyp=-1, d_mask=None):
+        """Device pointers (ints); asynchronous on the context's stream."""
+        K = np.ascontiguousarray(K, np.float64)
+        self._chk(lib.ktlvo_ransac_score_dev(self._h, d_X3, d_x2, n, d_Rt, H, _ptr(K), np.float32(thr_sq), d_counts,
+                                             mask_hyp, d_mask), "ktlvo_ransac_score_dev")
 
     def solve_pnp_ransac(self, X3, x2, max_iters=300, reproj=0.1, confidence=float(np.float32(0.99))):
         X3 = np.ascontiguousarray(X3, np.float32).reshape(-1, 3)

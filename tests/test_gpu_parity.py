@@ -470,6 +470,20 @@ def test_ransac_score_counts_exact(make_ctx, oracle):
             if h == 3:
                 assert np.array_equal(mask, m)
     assert counts.max() > 50
+    # the device-pointer form of the same call: arrays resident in HBM, nothing synchronised inside
+    import torch
+    dX, dx = torch.from_numpy(g["X3"].astype(np.float32)).cuda(), torch.from_numpy(g["x2"].astype(np.float32)).cuda()
+    dRt = torch.from_numpy(Rt).cuda()
+    dcnt = torch.full((H,), -1, dtype=torch.int32, device="cuda")
+    dmask = torch.zeros(len(g["X3"]), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.ransac_score_dev(dX.data_ptr(), dx.data_ptr(), len(g["X3"]), dRt.data_ptr(), H, g["K"], thr_sq, dcnt.data_ptr(),
+                         3, dmask.data_ptr())
+    ctx.sync()
+    assert np.array_equal(dcnt.cpu().numpy(), counts) and np.array_equal(dmask.cpu().numpy(), mask)
+    ctx.ransac_score_dev(dX.data_ptr(), dx.data_ptr(), 0, dRt.data_ptr(), H, g["K"], thr_sq, dcnt.data_ptr())
+    ctx.sync()
+    assert not dcnt.cpu().numpy().any()      # no points: every count is zero
 
 
 def test_ransac_score_large_batch(make_ctx, oracle):
