@@ -3,8 +3,8 @@
 // TermCriteria(COUNT|EPS, 30, 0.01), flags 0, minEigThreshold 1e-4).
 //
 // One 64-lane wavefront tracks one feature through all pyramid levels.  The 21x21 window is cut
-// into 63 horizontal runs of 7 pixels (21 rows x 3 runs); lane l owns run (row l % 21,
-// columns 7*(l / 21) ..+6), lane 63 idles.  A lane keeps its seven template values I, Ix, Iy in
+// into 63 horizontal runs of 7 pixels (21 rows x 3 runs); lane l owns run (row l / 3,
+// columns 7*(l % 3) ..+6), lane 63 idles.  A lane keeps its seven template values I, Ix, Iy in
 // registers for the whole level, so the template never touches LDS; per Gauss-Newton step a
 // lane fetches two 8-byte runs of the next image (rows r and r+1) and forms its seven bilinear
 // samples from them with v_perm_b32 + v_dot2 (two taps per instruction).  The 2x2 tensor and the
@@ -355,8 +355,10 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     const float ppx = a.prev[2 * gp], ppy = a.prev[2 * gp + 1];
 
     const bool active = lane < 63;
-    const int c = active ? lane / 21 : 0;
-    const int r = active ? lane - 21 * c : 0;
+    // Row-major: the three lanes of a window row are neighbours, so the four lanes the memory pipeline
+    // takes together touch two cache lines instead of four (1.8 % faster than run-major on the same box).
+    const int r = active ? lane / 3 : 0;
+    const int c = active ? lane - 3 * r : 0;
     const int cx = c * RUN;
     const float halfWin = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
