@@ -236,6 +236,55 @@ def run_ransac(a, rank, world, local, dev):
     ctx.close()
 
 
+def cpu_baseline(frames, pts, max_level, budget_s):
+    """The oracle (a port of the OpenCV path the reference calls) timed on the host cores: per
+    pair both pyramids, the previous image's Scharr planes and the LK loop, as one
+    cv::calcOpticalFlowPyrLK call does.  Bounded sample: the first pairs of the same workload,
+    repeated until the time budget is spent."""
+    import oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
+    n_pairs = min(len(frames) - 1, 4)
+
+    def timed(threads, budget):
+        tracked, t0, reps = 0, time.perf_counter(), 0
+        while True:
+            for i in range(n_pairs):
+                pa = O.Pyramid(frames[i], max_level, WIN, True)
+                pb = O.Pyramid(frames[i + 1], max_level, WIN, False)
+                _, st, _ = O.pyrlk(pa, pb, pts[i], WIN, max_level, nthreads=threads)
+                tracked += int(st.sum())
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget or reps >= 1000:
+                return tracked / el, reps, el
+
+    v_all, reps, el = timed(cores, budget_s)
+    v_one, reps1, el1 = timed(1, max(1.0, budget_s * 0.3))
+    # Gauss-Newton steps per level of the first pair (levels listed from level 0 up)
+    it, _ = O.lk_iterations(O.Pyramid(frames[0], max_level, WIN, True), O.Pyramid(frames[1], max_level, WIN, False),
+                            pts[0], max_level=max_level)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": v_all, "unit": "tracked features/s", "cores": cores, "kind": "port",
+            "sample": "first %d frame pairs x %d features of the same workload, %d repetitions, %.1f s; "
+                      "pyramids + Scharr + LK per pair (one calcOpticalFlowPyrLK each), points range-split "
+                      "over %d threads" % (n_pairs, pts.shape[1], reps, el, cores),
+            "single_thread": {"value": v_one, "cores": 1, "sample": "%d repetitions, %.1f s" % (reps1, el1)},
+            "cpu_model": model,
+            "lk_iterations_per_level_mean": [float(x) for x in it.mean(1)],
+            "lk_iterations_per_feature_mean": float(it.sum(0).mean())}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))

@@ -101,3 +101,23 @@ def test_parallel_frame_renderer_matches_serial():
     for f, img in enumerate(frames):
         assert img.dtype == np.uint8 and img.shape == (96, 160)
         assert np.array_equal(img, scene.render(f))
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_host():
+    """bench.py's CPU leg (the oracle timed on a bounded sample) needs no GPU; run it on two tiny frames."""
+    import importlib.util
+    import os
+    import numpy as np
+    from slam_amd import synth
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in ("main", "parse", "run_sequence", "run_ransac", "cpu_baseline", "measured_traffic"):
+        assert callable(getattr(bench, name)), name
+    a, b = synth.texture_pair(320, 240, 5, 1.5, -0.5, noise=True)
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(30, 290, 64), rng.uniform(30, 210, 64)], 1).astype(np.float32)[None]
+    out = bench.cpu_baseline([a, b], pts, 4, 0.2)
+    assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
+    assert len(out["lk_iterations_per_level_mean"]) >= 3 and out["single_thread"]["value"] > 0
