@@ -114,3 +114,36 @@ def test_contexts_on_concurrent_host_threads(make_ctx):
     assert all(o is not None for o in out)
     assert out[1] == out[0] and out[2] == out[0]
     assert len(out[0][-1][0]) > 100 * 24
+
+
+def test_hundred_frame_sequence_trajectory(make_ctx, oracle):
+    """BASELINE configs[0] shape: 100 stereo frames through tracker + pose on the GPU and through the
+    oracle's restatement of the two callbacks.  Last-bit differences of the LK float sums may flip a
+    gate for a single feature over such a run, so the bar is on the trajectories: each within 2 % of
+    the path length of the ground truth, and within 1 % of each other."""
+    W, H, NF = 1242, 375, 100
+    scene = synth.CorridorScene(W, H, seed=0x5EED0001)
+    ctx = make_ctx()
+    otr = oracle.Tracker(oracle.default_config(nthreads=16))
+    g_traj, o_traj, gt = [], [], []
+    Tgt = np.eye(4)
+    same_sets = 0
+    for f in range(NF):
+        L, R = scene.stereo_pair(f)
+        gl, gc, gkf = ctx.track_stereo_frame(L, R)
+        ol, oc, okf = otr.track(L, R)
+        if f == 0:
+            continue
+        same_sets += int(len(gl) == len(ol) and np.array_equal(gl["ind"], ol["ind"]))
+        _, _, gTg = ctx.estimate_pose(gl, gc)
+        _, _, oTg = otr.estimate_pose(ol, oc)
+        g_traj.append(gTg[:3, 3].copy())
+        o_traj.append(oTg[:3, 3].copy())
+        Tgt = Tgt @ scene.relative_pose(f - 1, f)
+        gt.append(Tgt[:3, 3].copy())
+    g_traj, o_traj, gt = np.array(g_traj), np.array(o_traj), np.array(gt)
+    path = float(np.abs(gt[-1]).max())
+    assert path > 70.0
+    assert _ate(g_traj, gt) < 0.02 * path and _ate(o_traj, gt) < 0.02 * path, (_ate(g_traj, gt), _ate(o_traj, gt))
+    assert _ate(g_traj, o_traj) <= 0.01 * path, _ate(g_traj, o_traj)
+    assert same_sets >= 0.9 * (NF - 1), same_sets     # in practice every frame keeps the same features
