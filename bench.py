@@ -95,6 +95,9 @@ def parse():
                          "synthetic sequence per rank, trajectories gathered (BASELINE configs[0]/[3]); ransac: "
                          "batched hypothesis scoring, 1024 hypotheses x 8000 points (configs[2])")
     ap.add_argument("--frames", type=int, default=20, help="sequence workload: stereo frames per rank")
+    ap.add_argument("--rank-offset", type=int, default=0,
+                    help="sequence workload: added to the rank when choosing its sequence (lets one GPU replay rank r's input)")
+    ap.add_argument("--dump-trajectories", default="", help="sequence workload: rank 0 saves the gathered poses here (.npy)")
     ap.add_argument("--streams", type=int, default=1,
                     help="sequence workload: tracker instances per GPU, one host thread and one HIP stream each")
     return ap.parse_args()
@@ -104,7 +107,7 @@ def run_sequence(a, rank, world, local, dev):
     """Stereo tracker + RANSAC pose on one synthetic 1242x375 corridor sequence per rank; every rank
     runs its own sequence (seed + rank) and the 4x4 poses are gathered with one all_gather."""
     W, H = 1242, 375
-    scene = synth.CorridorScene(W, H, seed=shard.rank_seed(0x5EED0010, rank))
+    scene = synth.CorridorScene(W, H, seed=shard.rank_seed(0x5EED0010, rank + a.rank_offset))
     frames = [scene.stereo_pair(f) for f in range(a.frames)]
     # --streams S: S tracker instances (contexts, each with its own HIP stream) driven by S host threads
     # on this rank's GPU, all fed the same sequence; a single instance is latency-bound and leaves most
@@ -159,6 +162,8 @@ def run_sequence(a, rank, world, local, dev):
     rec = torch.tensor([float(a.frames), float(tracked), float(keyframes), np.sqrt(ate2 / max(a.frames - 1, 1)),
                         float(np.abs(gt[:3, 3]).max()), elapsed, 0.0, 0.0], dtype=torch.float64, device=dev)
     recs = shard.gather_records(rec, world)
+    if rank == 0 and a.dump_trajectories:
+        np.save(a.dump_trajectories, np.asarray(traj))   # [world, frames, 16], for the sharding parity test
     if rank == 0:
         print(json.dumps({
             "metric": "stereo frames/sec, ktl_vo frontend + RANSAC pose (1242x375, reference parameters)",

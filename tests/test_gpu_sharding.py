@@ -1,0 +1,38 @@
+"""Sharding parity on one GPU box: two ranks (gloo, both on GPU 0: the rehearsal mode of bench.py) run
+the sequence workload, each on its own sequence, and the gathered trajectories must be byte-equal to
+what single-rank runs of the same two sequences give."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_two_rank_gather_equals_single_rank_runs(tmp_path):
+    nf = 8
+    common = ["bench.py", "--workload", "sequence", "--frames", str(nf)]
+    two = tmp_path / "two.npy"
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", "29641"] + common + ["--gpus", "2", "--dump-trajectories", str(two)],
+               {"KTLVO_BENCH_REHEARSAL": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert out["n_gpus"] == 2 and out["trajectory_shape"] == [2, nf, 16] and len(out["per_rank"]) == 2
+    gathered = np.load(two)
+    for r in range(2):
+        one = tmp_path / ("one%d.npy" % r)
+        o = _run([sys.executable] + common + ["--rank-offset", str(r), "--dump-trajectories", str(one)])
+        assert o["per_rank"][0]["tracked_points"] == out["per_rank"][r]["tracked_points"]
+        assert np.load(one)[0].tobytes() == gathered[r].tobytes(), r
+    assert not np.array_equal(gathered[0], gathered[1])    # the ranks really ran different sequences
