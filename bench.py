@@ -3,9 +3,10 @@
 
 Metric (BASELINE.json): tracked features/sec @1241x376, 21x21 pyramidal LK, maxLevel 4.
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident
-in HBM: P consecutive frame pairs of a synthetic KITTI-shaped sequence (BASELINE configs[1]:
-2000 Shi-Tomasi corners per frame, frame-pair stream), i.e. the Gaussian pyramids of the P+1
-frames (pyr_down_u8) and P calcOpticalFlowPyrLK-equivalents in one launch (pyrlk_track_w21).
+in HBM: P consecutive frame pairs of each of Q synthetic KITTI-shaped sequences (BASELINE
+configs[1]: 2000 Shi-Tomasi corners per frame, frame-pair stream), i.e. the Gaussian pyramids of
+the Q(P+1) frames (pyr_down_u8, scharr_planes) and QP calcOpticalFlowPyrLK-equivalents in one
+launch (pyrlk_track_w21).
 A tracked feature is a point that leaves that call with status 1.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -77,7 +78,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=127, help="frame pairs per step (<= 127)")
+    ap.add_argument("--pairs", type=int, default=127, help="consecutive frame pairs per sequence and step (<= 127)")
+    ap.add_argument("--sequences", type=int, default=2,
+                    help="synthetic sequences per rank and step (sequences x pairs <= 256, the capacity of one LK launch)")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--height", type=int, default=376)
@@ -89,6 +92,9 @@ def parse():
                          "step's pyramid build overlaps the previous step's LK tail")
     ap.add_argument("--skip-secondary", action="store_true",
                     help="leave out the maxLevel-3 run (profiling passes: one launch shape per kernel)")
+    ap.add_argument("--time-kernels", choices=["lk", "all"], default="lk",
+                    help="kernels bracketed by HIP events inside the timed region: the dominant one (default; the "
+                         "pyramid kernels are then timed in an untimed pass) or all three")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
     ap.add_argument("--workload", choices=["pairs", "sequence", "ransac"], default="pairs",
                     help="pairs: the headline frame-pair stream (default); sequence: stereo tracker + pose on a "
@@ -322,10 +328,17 @@ def main():
     assert 1 <= P <= 127   # the synthetic corridor (120 m, 0.8 m per frame) ends after about 130 frames
     pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
 
-    # ---- synthetic input: one sequence per rank -----------------------------------------------
+    # ---- synthetic input: Q sequences per rank, P consecutive pairs of each ---------------------
+    # (the corridor ends after about 130 frames and one LK launch takes up to 256 pairs: two sequences
+    # fill it, which halves the share of the launch's ramp and drain)
+    Q = a.sequences
+    assert 1 <= Q and Q * P <= 256
     scene = synth.CorridorScene(W, H, seed=shard.rank_seed(a.seed, rank))
-    frames = synth.render_corridor_frames(W, H, shard.rank_seed(a.seed, rank), P + 1, workers=8)
-    cfg = K.default_config(width=W, height=H, num_slots=P + 1, max_level=a.max_level, max_points=max(NF, 1024),
+    frames = []
+    for q in range(Q):
+        frames += synth.render_corridor_frames(W, H, shard.rank_seed(a.seed + 0x1000 * q, rank), P + 1, workers=8)
+    NI, NP = Q * (P + 1), Q * P          # images and pairs per step
+    cfg = K.default_config(width=W, height=H, num_slots=NI, max_level=a.max_level, max_points=max(NF, 1024),
                            cx=scene.cx, cy=scene.cy)
     ctxs = [K.Context(cfg, device=local) for _ in range(max(1, a.pipeline))]
     ctx = ctxs[0]
@@ -348,9 +361,12 @@ def main():
         c.sync()
     # corners of every pair's first frame, from the product detector (Shi-Tomasi, whole frame)
     gp = K.gftt_params(NF, 0.01, a.min_dist, 3, 0, 0.0)
-    pts = np.zeros((P, NF, 2), np.float32)
+    slots = list(range(NI))
+    prev_slots = [q * (P + 1) + i for q in range(Q) for i in range(P)]
+    next_slots = [s + 1 for s in prev_slots]
+    pts = np.zeros((NP, NF, 2), np.float32)
     min_dist_used = a.min_dist
-    for i in range(P):
+    for j, i in enumerate(prev_slots):
         md = a.min_dist
         (xy, _), = ctx.detect_gftt(i, [(0, 0, W, H)], gp)
         while len(xy) < NF:
@@ -361,14 +377,12 @@ def main():
                 raise SystemExit("frame %d yields %d corners < %d even at minDistance 1" % (i, len(xy), NF))
             (xy, _), = ctx.detect_gftt(i, [(0, 0, W, H)], K.gftt_params(NF, 0.01, md, 3, 0, 0.0))
         min_dist_used = min(min_dist_used, md)
-        pts[i] = xy
+        pts[j] = xy
     d_prev = torch.from_numpy(pts).to(dev)
-    outs = [(torch.zeros_like(d_prev), torch.zeros((P, NF), dtype=torch.uint8, device=dev),
-             torch.zeros((P, NF), dtype=torch.float32, device=dev)) for _ in ctxs]
+    outs = [(torch.zeros_like(d_prev), torch.zeros((NP, NF), dtype=torch.uint8, device=dev),
+             torch.zeros((NP, NF), dtype=torch.float32, device=dev)) for _ in ctxs]
     d_next, d_status, d_err = outs[0]
     lk = K.lk_params(WIN, a.max_level)
-    slots = list(range(P + 1))
-    prev_slots, next_slots = slots[:-1], slots[1:]
     step_no = [0]
 
     def step():
@@ -389,8 +403,11 @@ def main():
     for _ in range(max(a.warmup, len(ctxs))):
         step()
     fence()
+    # In the timed region only the dominant kernel is bracketed by events (an event pair costs a few
+    # microseconds of stream time; three pairs per step are 3-4 % of this step); the two pyramid kernels
+    # are timed in a short untimed pass afterwards.
     for c in ctxs:
-        c.profile_enable(True)
+        c.profile_enable(True if a.time_kernels == "all" else 2 << K.K_PYRLK)
         c.profile_reset()
     fence()
     step_no[0] = 0
@@ -402,6 +419,14 @@ def main():
     k3_ms = k3_n = k1_ms = k1_n = k2_ms = k2_n = 0
     for c in ctxs:
         m, n = c.profile_get(K.K_PYRLK); k3_ms += m; k3_n += n
+    if a.time_kernels != "all":
+        for c in ctxs:
+            c.profile_enable(True)
+            c.profile_reset()
+        for _ in range(max(3 * len(ctxs), a.steps // 4)):
+            step()
+        fence()
+    for c in ctxs:
         m, n = c.profile_get(K.K_PYRDOWN); k1_ms += m; k1_n += n
         m, n = c.profile_get(K.K_SCHARR); k2_ms += m; k2_n += n
         c.profile_enable(False)
@@ -428,7 +453,7 @@ def main():
         ml3 = {"value": tr3 * n3 / t3, "unit": "tracked features/s", "steps": n3, "tracked_per_step": tr3}
         ctx.build_pyramids(slots)   # leave the slots as the main run built them
         fence()
-    rec = torch.tensor([float(P * NF), float(tracked), float(P), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
+    rec = torch.tensor([float(NP * NF), float(tracked), float(NP), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
                        dtype=torch.float64, device=dev)
     t_max = shard.max_over_ranks(elapsed, dev, world)
     recs = shard.gather_records(rec, world)        # the only collective: fixed-size per-rank statistics
@@ -438,22 +463,26 @@ def main():
         total_tracked, total_in, value = agg["tracked_per_step"], agg["features_in_per_step"], agg["value"]
         bpf = lk_bytes_per_feature(levels)
         k3_avg_s = (k3_ms / max(k3_n, 1)) * 1e-3
-        feats_per_launch = P * NF
+        feats_per_launch = NP * NF
         achieved = bpf * feats_per_launch / k3_avg_s / 1e9 if k3_avg_s > 0 else 0.0
         lv_bytes, w_, h_ = 0, W, H                  # bytes of one image's pyramid
         for _ in range(levels):
             lv_bytes += w_ * h_
             w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
         traffic, traffic_src, pmc = measured_traffic("pyrlk_track_w21", feats_per_launch)
-        # what the kernel is really limited by: vector-ALU issue.  A wave64 VALU instruction holds a
-        # SIMD's ALU for 4 cycles; 256 CUs x 4 SIMDs; shader clock measured with s_memtime under
-        # this kernel: 2.39 GHz.  Instruction count from the same PMC summary as `traffic`.
+        # what the kernel is really limited by: vector-ALU issue.  A 64-lane VALU instruction holds a
+        # 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs; 2.4 GHz is the part's peak engine clock.
+        # Instruction count from the same PMC summary as `traffic`.  A fraction at or slightly above 1
+        # means that every issue slot is taken (some counted instructions, v_readlane for one, need
+        # fewer than 4 cycles).
         valu = None
         if pmc and pmc.get("SQ_INSTS_VALU") and k3_avg_s > 0:
+            per_simd_ns = pmc["SQ_INSTS_VALU"] / (1024 * k3_avg_s * 1e9)
             valu = {"insts_per_feature": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
                     "vmem_insts_per_feature": pmc.get("SQ_INSTS_VMEM", 0.0) / pmc["SQ_WAVES"],
-                    "issue_busy_frac": pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.39e9 * k3_avg_s),
-                    "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.39 GHz x kernel time); "
+                    "wave_insts_per_simd_per_ns": per_simd_ns,
+                    "issue_busy_frac": per_simd_ns * 4.0 / 2.4,
+                    "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
                             "counters from " + traffic_src}
         out = {
             "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
@@ -475,11 +504,12 @@ def main():
                                 "BASELINE configs[2] shape: " if (W, H, NF) == (1920, 1080, 8000) else
                                 "BASELINE configs[4] shape: " if (W, H, NF) == (3840, 2160, 16384) else "",
                                 W, H, NF, a.max_level, levels),
-                "pairs_per_step": P,
+                "pairs_per_step": NP,
+                "sequences_per_step": Q,
                 "pipeline_contexts": len(ctxs),
                 "features_per_pair": NF,
                 "min_distance_rank0": min_dist_used,
-                "per_gpu_sequence": "corridor seed 0x%X + rank" % a.seed,
+                "per_gpu_sequence": "corridor seeds 0x%X + 0x1000 q + rank, q < %d" % (a.seed, Q),
                 "features_in_per_step": total_in,
                 "tracked_per_step": total_tracked,
                 "pairs_per_s": agg["pairs_per_s"],
@@ -505,26 +535,26 @@ def main():
                 "features_per_launch": feats_per_launch,
             },
             "kernels": {
-                "pyr_down_u8": {"avg_ms_per_step": k1_ms / max(k1_n, 1), "images_per_step": P + 1,
+                "pyr_down_u8": {"avg_ms_per_step": k1_ms / max(k1_n, 1), "images_per_step": NI,
                                 "algorithmic_bytes_per_image": pyr_bytes,
-                                "achieved_GBps": pyr_bytes * (P + 1) / max(k1_ms / max(k1_n, 1) * 1e-3, 1e-12) / 1e9},
-                "scharr_planes": {"avg_ms_per_step": k2_ms / max(k2_n, 1), "images_per_step": P + 1,
+                                "achieved_GBps": pyr_bytes * NI / max(k1_ms / max(k1_n, 1) * 1e-3, 1e-12) / 1e9},
+                "scharr_planes": {"avg_ms_per_step": k2_ms / max(k2_n, 1), "images_per_step": NI,
                                   "algorithmic_bytes_per_image": 5 * lv_bytes,   # 1 B read + 4 B written per pixel
-                                  "achieved_GBps": 5 * lv_bytes * (P + 1) / max(k2_ms / max(k2_n, 1) * 1e-3, 1e-12) / 1e9},
+                                  "achieved_GBps": 5 * lv_bytes * NI / max(k2_ms / max(k2_n, 1) * 1e-3, 1e-12) / 1e9},
                 "pyrlk_track_w21": {"avg_ms_per_step": k3_ms / max(k3_n, 1)},
             },
             "h2d_inclusive": {"value": total_tracked / world / (t_max / a.steps + t_h2d),
                               "value_pinned_source": total_tracked / world / (t_max / a.steps + t_h2d_pinned),
                               "upload_ms": {"pageable_source": t_h2d * 1e3, "pinned_source": t_h2d_pinned * 1e3},
                               "note": "rank-0 rate if the %d frames of a step were uploaded from host memory "
-                                      "(pinned staging ring) every step (%.1f ms); never the headline value" % (P + 1, t_h2d * 1e3)},
+                                      "(pinned staging ring) every step (%.1f ms); never the headline value" % (NI, t_h2d * 1e3)},
             "per_rank": [{"features_in": r[0], "tracked": r[1], "k3_ms": r[3], "k1_ms": r[5], "elapsed_s": r[7]}
                          for r in recs.tolist()],
         }
         if ml3 is not None:
             out["max_level_3"] = ml3
         if world == 1 and a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(frames, pts, a.max_level, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(frames[:P + 1], pts[:P], a.max_level, a.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

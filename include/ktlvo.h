@@ -237,6 +237,9 @@ int ktlvo_wire_transform(const float T[16], const ktlvo_ros_header *h, uint8_t *
 /* With profiling on, every launch of the kernels listed in the enum above is bracketed by
  * hipEvents on the context's stream; ktlvo_profile_get synchronises and returns the summed
  * device time and launch count since the last ktlvo_profile_reset. */
+/* on: 0 = off, 1 = every kernel, otherwise a mask with bit (1 + kernel id) set for each kernel to
+ * time (an event pair costs a few microseconds of stream time, which matters to a step of a few
+ * launches). */
 int ktlvo_profile_enable(ktlvo_ctx *ctx, int on);
 int ktlvo_profile_reset(ktlvo_ctx *ctx);
 int ktlvo_profile_get(ktlvo_ctx *ctx, int kernel_id, double *total_ms, long long *launches);

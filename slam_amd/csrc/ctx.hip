@@ -25,7 +25,7 @@ static hipEvent_t take_event(ktlvo_ctx *ctx) {
 }
 
 ProfScope::ProfScope(ktlvo_ctx *c, int k) : ctx(c), kid(k) {
-    if (!ctx->prof.on) return;
+    if (!(ctx->prof.mask & (1u << kid))) return;
     a = take_event(ctx);
     b = take_event(ctx);
     if (a && b) (void)hipEventRecord(a, ctx->stream);
@@ -234,7 +234,8 @@ extern "C" const char *ktlvo_last_error(const ktlvo_ctx *ctx) { return ctx ? ctx
 extern "C" int ktlvo_profile_enable(ktlvo_ctx *ctx, int on) {
     if (!ctx) return KTLVO_ERR_INVALID;
     KTLVO_BIND(ctx);
-    ctx->prof.on = on != 0;
+    // 0: off; 1: every kernel; otherwise bit (1 + kernel id) selects a kernel
+    ctx->prof.mask = on == 0 ? 0u : on == 1 ? ~0u : ((unsigned)on >> 1);
     return KTLVO_OK;
 }
 

@@ -37,7 +37,7 @@ struct PairList { // slot ids; ktlvo_create limits num_slots to 65536
 };
 
 struct Profiler {
-    bool on = false;
+    unsigned mask = 0;                            // bit k: launches of kernel id k are bracketed by events
     std::vector<hipEvent_t> pool;                 // recycled events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KTLVO_K_COUNT];
     double total_ms[KTLVO_K_COUNT] = {0, 0, 0, 0, 0};
