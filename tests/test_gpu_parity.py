@@ -578,3 +578,25 @@ def test_device_p3p_matches_host_p3p(make_ctx, oracle):
     assert a["ok"] and b["ok"] and abs(a["n_inliers"] - b["n_inliers"]) <= 2
     assert np.abs(a["rvec"] - b["rvec"]).max() < 1e-8 and np.abs(a["tvec"] - b["tvec"]).max() < 1e-8
     assert np.abs(b["rvec"] - np.array([0.01, -0.02, 0.005])).max() < 2e-3
+
+
+def test_profiling_mask_selects_kernels(make_ctx, klib):
+    W, H = 320, 240
+    a, b = synth.texture_pair(W, H, 3, 1.0, 0.5)
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, a)
+    ctx.upload_image(1, b)
+    pts = np.array([[100.0, 100.0], [200.0, 120.0]], np.float32)
+    for mode, expect_pyr in ((True, True), (2 << klib.K_PYRLK, False)):
+        ctx.profile_enable(mode)
+        ctx.profile_reset()
+        ctx.build_pyramids([0, 1])
+        ctx.pyrlk(0, 1, pts)
+        ms_lk, n_lk = ctx.profile_get(klib.K_PYRLK)
+        ms_pd, n_pd = ctx.profile_get(klib.K_PYRDOWN)
+        assert n_lk == 1 and ms_lk > 0
+        assert (n_pd == 1) == expect_pyr, (mode, n_pd)
+    ctx.profile_enable(False)
+    ctx.profile_reset()
+    ctx.pyrlk(0, 1, pts)
+    assert ctx.profile_get(klib.K_PYRLK)[1] == 0
