@@ -4,7 +4,7 @@ usage: fuzz_case.py seed cases"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import oracle as O
 from slam_amd import lib as K
 import test_gpu_fuzz as T
