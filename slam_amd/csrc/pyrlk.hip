@@ -81,9 +81,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 struct Sum2 {
     float a, b;
 };
-__device__ __forceinline__ Sum2 wave_sum2(float a, float b) {
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+// The operands are exact integer partial sums of at most 2^30 in magnitude, so the first fold (two
+// lanes) is done in integers and only its result is converted: one conversion instead of two, and
+// one rounding fewer.
+__device__ __forceinline__ Sum2 wave_sum2(int a, int b) {
+    const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
+    float v = (float)(int)(sw[0] + sw[1]);
     v = dpp_add<0xB1, 0xF>(v);
     v = dpp_add<0x4E, 0xF>(v);
     v = dpp_add<0x141, 0xF>(v);
@@ -133,7 +136,9 @@ __device__ __forceinline__ Weights bilinear_weights(float x, float y, float floo
     const uint32_t m00 = __float_as_uint(Y.x * Y.y + 8388608.f);
     const uint32_t m01 = __float_as_uint(cross.x), m10 = __float_as_uint(cross.y);
     // 16384 - iw00 - iw01 - iw10 in the low 16 bits (the 0x4B000000 exponent fields cancel mod 2^32)
-    const uint32_t m11 = (16384u + 3u * 0x4B000000u) - (m00 + m01 + m10);
+    uint32_t m3; // m00 + m01 + m10 in one instruction; the s_nop covers the packed result read by asm
+    asm("s_nop 0\n\tv_add3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(m00), "v"(m01), "v"(m10));
+    const uint32_t m11 = (16384u + 3u * 0x4B000000u) - m3;
     Weights w;
     w.wl = __builtin_amdgcn_perm(m10, m00, 0x05040100u);
     w.wr = __builtin_amdgcn_perm(m11, m01, 0x05040100u);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         }
         const Dot2 sxx = dot7x2(ixp, ixp, iyp);
         const int s11 = sxx.xy, s12 = sxx.xz, s22 = dot7(iyp, iyp);
-        const Sum2 sa = wave_sum2((float)s11, (float)s12);
+        const Sum2 sa = wave_sum2(s11, s12);
         const float A11 = sa.a * FLT_SCALE, A12 = sa.b * FLT_SCALE;
         const float A22 = wave_sum((float)s22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -465,7 +470,6 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         const float Ds = D * FLT_SCALE;
 
         // ---- Gauss-Newton iterations -----------------------------------------------------------
-        float pdx = 0.f, pdy = 0.f;
         // The rows fetched for one step serve the following steps as long as the window's integer
         // corner stays put, which is the rule once the first step or two of a level are done: only
         // the weights change then, and the step needs no memory access at all.  Hence two loops: the
@@ -473,61 +477,82 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         int have_x = INT_MIN, have_y = INT_MIN;
         Cols cols;
 #pragma unroll
-        for (int k = 0; k < 8; k++) asm("" : "=v"(cols.c[k])); // defined without a fill; read only once fetched
+        // defined without a fill, read only once fetched; the index operand keeps the eight statements
+        // distinct (identical ones are merged and then copied apart again), and they are not volatile, which
+        // would count as a store and turn the scalar loads of the level descriptors into vector loads
+        for (int k = 0; k < 8; k++) asm("; cols %1" : "=v"(cols.c[k]) : "i"(k));
         int j = 0;
-        bool more = a.max_count > 0;
         bool fetched = first_inside; // the rows for (inx, iny) are in jt, jb already
-        while (more) {
-            if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
-                if (level == 0) status = 0;
-                break;
+        bool stepped = false;        // nextPts[i] is only rewritten by a step
+        float backx = 0.f, backy = 0.f; // half of the last step, taken back when the steps alternate
+        // One step: reads the previous step (qx, qy), leaves its own in (dx, dy).  Returns 0 to go on
+        // with the same rows, 1 when the level is finished, 2 when the window corner has moved.
+        auto gn_step = [&](const float qx, const float qy, float &dx, float &dy) __attribute__((always_inline)) -> int {
+            w = bilinear_weights(nx, ny, flx, fly);
+            int dsum[RUN];
+            sample_sums(cols, w, Ineg, dsum);
+            const Packed7 dp = pack7_descale9(dsum); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
+            const Dot2 bb = dot7x2(dp, ixp, iyp);
+            const Sum2 bs = wave_sum2(bb.xy, bb.xz);
+            dx = (A12 * bs.b - A22 * bs.a) * Ds;
+            dy = (A12 * bs.a - A11 * bs.b) * Ds;
+            nx += dx; ny += dy;
+            // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
+            // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
+            const float step_sq = dx * dx + dy * dy;
+            if (step_sq <= a.eps_lo || (step_sq < a.eps_hi && (double)dx * dx + (double)dy * dy <= a.eps_sq)) return 1;
+            // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
+            // so "<= 0.01f" is the same predicate without leaving single precision
+            if (j > 0 && fabsf(dx + qx) <= 0.01f && fabsf(dy + qy) <= 0.01f) {
+                backx = dx * 0.5f; backy = dy * 0.5f;
+                return 1;
             }
-            if (!fetched) {
-                je = lane_off + (uint32_t)(iny * pitch + inx);
-                jt = fetch_run8(Jbase, je);
-                jb = fetch_run8(Jbase, je + pitch);
+            if (++j >= a.max_count) return 1;
+            flx = floorf(nx); fly = floorf(ny);
+            int kx, ky;
+            scalar_xy((int)flx, (int)fly, kx, ky);
+            if (kx != inx || ky != iny) { // new corner: bounds test and fetch in the outer loop
+                inx = kx; iny = ky;
+                return 2;
             }
-            fetched = false;
-            cols = col_pairs(align_run8(jt, je), align_run8(jb, je)); // pitch is a multiple of 4: both rows shift alike
-            have_x = inx; have_y = iny;
+            return 0;
+        };
+        // The step before the current one lives in (p1x, p1y) whenever the inner loop is entered; the
+        // loop is unrolled twice with the two register pairs changing roles, so that no step copies
+        // its result into "previous".
+        float p0x, p0y, p1x = 0.f, p1y = 0.f;
+        if (a.max_count > 0) {
             for (;;) {
-                w = bilinear_weights(nx, ny, flx, fly);
-                int dsum[RUN];
-                sample_sums(cols, w, Ineg, dsum);
-                const Packed7 dp = pack7_descale9(dsum); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
-                const Dot2 bb = dot7x2(dp, ixp, iyp);
-                const Sum2 bs = wave_sum2((float)bb.xy, (float)bb.xz);
-                const float dx = (A12 * bs.b - A22 * bs.a) * Ds;
-                const float dy = (A12 * bs.a - A11 * bs.b) * Ds;
-                nx += dx; ny += dy;
-                ox = nx + halfWin; oy = ny + halfWin;
-                // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
-                // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
-                const float step_sq = dx * dx + dy * dy;
-                if (step_sq <= a.eps_lo || (step_sq < a.eps_hi && (double)dx * dx + (double)dy * dy <= a.eps_sq)) {
-                    more = false;
+                if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
+                    if (level == 0) status = 0;
                     break;
                 }
-                // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
-                // so "<= 0.01f" is the same predicate without leaving single precision
-                if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-                    ox -= dx * 0.5f; oy -= dy * 0.5f;
-                    more = false;
-                    break;
+                if (!fetched) {
+                    je = lane_off + (uint32_t)(iny * pitch + inx);
+                    jt = fetch_run8(Jbase, je);
+                    jb = fetch_run8(Jbase, je + pitch);
                 }
-                if (++j >= a.max_count) {
-                    more = false;
-                    break;
-                }
-                pdx = dx; pdy = dy;
-                flx = floorf(nx); fly = floorf(ny);
-                int kx, ky;
-                scalar_xy((int)flx, (int)fly, kx, ky);
-                if (kx != inx || ky != iny) { // new corner: bounds test and fetch in the outer loop
-                    inx = kx; iny = ky;
-                    break;
+                fetched = false;
+                cols = col_pairs(align_run8(jt, je), align_run8(jb, je)); // pitch is a multiple of 4: both rows shift alike
+                have_x = inx; have_y = iny;
+                stepped = true;
+                for (;;) {
+                    int rc = gn_step(p1x, p1y, p0x, p0y);
+                    if (rc == 1) goto level_done;
+                    if (rc == 2) {
+                        p1x = p0x; p1y = p0y;
+                        break;
+                    }
+                    rc = gn_step(p0x, p0y, p1x, p1y);
+                    if (rc == 1) goto level_done;
+                    if (rc == 2) break;
                 }
             }
+        }
+    level_done:
+        if (stepped) { // nextPts[i] = nextPt + halfWin, then nextPts[i] -= delta * 0.5f where the steps alternated
+            ox = (nx + halfWin) - backx;
+            oy = (ny + halfWin) - backy;
         }
 
         // ---- final error (level 0 only) ------------------------------------------------------
