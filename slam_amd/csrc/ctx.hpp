@@ -17,11 +17,13 @@ constexpr int MAX_LEVELS = 8;
 // reflect-101 continuation of the level (what cv::buildOpticalFlowPyramid's copyMakeBorder
 // produces for `win` pixels), so the LK kernel never needs border index arithmetic.
 constexpr int PAD = 32;
+// The Scharr planes store SCHARR_GAIN times calcSharrDeriv's values (see scharr_planes and the LK template).
+constexpr int SCHARR_GAIN = 4;
 constexpr int MAX_BATCH = 256; // slots / pairs passed by value to one launch (kernel arguments are limited to 4 KiB)
 
 struct LevelDesc {
     uint8_t *origin;   // address of pixel (0,0)
-    uint32_t *dorigin; // Scharr plane, element (0,0): int16 dx | int16 dy << 16; zero outside the level
+    uint32_t *dorigin; // Scharr plane, element (0,0): int16 4 dx | int16 4 dy << 16; zero outside the level
     int w, h, pitch;   // pitch in elements (both planes); (x,y) addressable for x in [-PAD, w+PAD), y likewise
 };
 struct SlotDesc {

@@ -129,6 +129,9 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // three 16-byte row pieces of the padded image, whose frame supplies calcSharrDeriv's reflect-101
 // neighbours.  The arithmetic runs on packed int16 pairs (|values| <= 16 * 255):
 //   T = 3 (r0 + r2) + 10 r1,  dx[x] = T[x+1] - T[x-1];   D = r2 - r0,  dy[x] = 3 (D[x-1] + D[x+1]) + 10 D[x].
+// The planes hold FOUR TIMES these values (coefficients 12 and 40; |4 d| <= 64 * 255 still fits int16):
+// the tracker's bilinear sums then carry CV_DESCALE(sum, 14) in their upper 16 bits, where one byte
+// permute packs two of them.  ktlvo_download_scharr divides by four again.
 // Only the interior of the plane is written; its frame stays zero (copyMakeBorder BORDER_CONSTANT).
 __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, SlotList list, int n_levels) {
     const int level = blockIdx.y;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
     i16x2 o0[5], o1[5], o2[5], e0[4], e2[4];
     odd(r[0], o0); odd(r[1], o1); odd(r[2], o2);
     even(r[0], e0); even(r[2], e2);
-    const i16x2 three = {3, 3}, ten = {10, 10};
+    const i16x2 three = {3 * SCHARR_GAIN, 3 * SCHARR_GAIN}, ten = {10 * SCHARR_GAIN, 10 * SCHARR_GAIN};
     i16x2 T[5], Do[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -319,5 +322,6 @@ extern "C" int ktlvo_download_scharr(ktlvo_ctx *ctx, int slot, int level, int16_
     KTLVO_HIP(ctx, hipMemcpy2DAsync(dst, (size_t)L.w * 4, L.dorigin, (size_t)L.pitch * 4, (size_t)L.w * 4, L.h,
                                     hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0, n = (size_t)L.w * L.h * 2; i < n; i++) dst[i] = (int16_t)(dst[i] / SCHARR_GAIN); // exact: stored as multiples
     return KTLVO_OK;
 }

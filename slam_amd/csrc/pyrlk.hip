@@ -9,7 +9,7 @@
 // lane fetches two 8-byte runs of the next image (rows r and r+1) and forms its seven bilinear
 // samples from them with v_perm_b32 + v_dot2 (two taps per instruction).  The 2x2 tensor and the
 // mismatch vector are summed across the wave with DPP row operations.  Derivatives come from the
-// Scharr planes built with the pyramid (int16 dx|dy per pixel, zero outside the level).
+// Scharr planes built with the pyramid (int16 4 dx | 4 dy per pixel, zero outside the level).
 //
 // The kernel is VALU-bound (rocprof: VALU busy > 95 %), so the design minimises instructions per
 // pixel and per iteration rather than bytes: images and planes stay L2-resident.
@@ -226,8 +226,7 @@ __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, cons
 }
 // The same with one accumulator start for all seven samples (a rounding constant) and the descale
 // shift as a parameter.
-template <int SHIFT>
-__device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, int acc0, int (&v)[7]) {
+__device__ __forceinline__ void sample_sums(const Cols &k, const Weights &w, int acc0, int (&d)[7]) {
     int d0, d1, d2, d3, d4, d5, d6;
     asm("v_dot2_i32_i16 %0, %7, %15, %17\n\t"
         "v_dot2_i32_i16 %1, %8, %15, %17\n\t"
@@ -247,8 +246,14 @@ __device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, int 
         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6)
         : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
           "v"(w.wl), "v"(w.wr), "v"(acc0));
-    v[0] = d0 >> SHIFT; v[1] = d1 >> SHIFT; v[2] = d2 >> SHIFT; v[3] = d3 >> SHIFT; v[4] = d4 >> SHIFT; v[5] = d5 >> SHIFT;
-    v[6] = d6 >> SHIFT;
+    d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = d4; d[5] = d5; d[6] = d6;
+}
+template <int SHIFT>
+__device__ __forceinline__ void sample_run(const Cols &k, const Weights &w, int acc0, int (&v)[7]) {
+    int d[7];
+    sample_sums(k, w, acc0, d);
+#pragma unroll
+    for (int i = 0; i < 7; i++) v[i] = d[i] >> SHIFT;
 }
 // int16 pairs (v0, v1), (v2, v3), (v4, v5), (v6, 0) of seven values that fit 16 bits
 struct Packed7 {
@@ -274,6 +279,14 @@ __device__ __forceinline__ Packed7 pack7_descale9(const int (&d)[7]) {
         r.p[j] = __builtin_bit_cast(uint32_t, h >> (short)1);
     }
     r.p[3] = ((uint32_t)d[6] >> 9) & 0xFFFFu;
+    return r;
+}
+// pack7 of the upper halves (d[i] >> 16) of seven sums
+__device__ __forceinline__ Packed7 pack7_high(const int (&d)[7]) {
+    Packed7 r;
+#pragma unroll
+    for (int j = 0; j < 3; j++) r.p[j] = __builtin_amdgcn_perm((uint32_t)d[2 * j + 1], (uint32_t)d[2 * j], 0x07060302u);
+    r.p[3] = (uint32_t)d[6] >> 16;
     return r;
 }
 // (sum of x[i] * y[i], sum of x[i] * z[i]) over the seven values, exact in int32
@@ -436,11 +449,14 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
                 cxp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x05040100u);
                 cyp.c[k] = __builtin_amdgcn_perm(d1[k], d0[k], 0x07060302u);
             }
-            int ixv[RUN], iyv[RUN]; // CV_DESCALE(sum, 14)
-            sample_run<14>(cxp, w, 1 << 13, ixv);
-            sample_run<14>(cyp, w, 1 << 13, iyv);
-            ixp = pack7(ixv);
-            iyp = pack7(iyv);
+            // The planes hold 4 dx, 4 dy, so a sum started at 2^15 has CV_DESCALE(sum / 4, 14) in its
+            // upper half, and one permute packs two of them.
+            static_assert(SCHARR_GAIN == 4, "the descale below assumes planes scaled by four");
+            int ixs[RUN], iys[RUN];
+            sample_sums(cxp, w, 1 << 15, ixs);
+            sample_sums(cyp, w, 1 << 15, iys);
+            ixp = pack7_high(ixs);
+            iyp = pack7_high(iys);
         }
         const Dot2 sxx = dot7x2(ixp, ixp, iyp);
         const int s11 = sxx.xy, s12 = sxx.xz, s22 = dot7(iyp, iyp);
