@@ -122,15 +122,16 @@ struct Weights {
     uint32_t wl, wr;
 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ Weights bilinear_weights(float x, float y, float floor_x, float floor_y) {
-    // OpenCV: a = x - floor(x), b = y - floor(y); iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14),
-    // iw10 = cvRound((1-a)*b*2^14).  Scaling by 2^14 is exact and commutes with the roundings of 1 - b
+__device__ __forceinline__ Weights bilinear_weights(f32x2 frac) {
+    // frac = (a, b) = (x - floor(x), y - floor(y)) as OpenCV forms them;
+    // iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14), iw10 = cvRound((1-a)*b*2^14).
+    // Scaling by 2^14 is exact and commutes with the roundings of 1 - b
     // and of the products, so it is applied to b first; adding 2^23 rounds a float in [0, 2^23) to the
     // nearest-even integer and leaves it in the low mantissa bits.  Written on float pairs so that the
     // compiler emits packed instructions: X = (a, b 2^14), Y = (1 - a, (1 - b) 2^14), and one
     // v_pk_mul_f32 with crossed halves yields (a * Y.y, X.y * (1 - a)).
     const f32x2 scale = {1.f, 16384.f}, magic = {8388608.f, 8388608.f};
-    const f32x2 X = (f32x2{x, y} - f32x2{floor_x, floor_y}) * scale;
+    const f32x2 X = frac * scale;
     const f32x2 Y = scale - X;
     const f32x2 cross = __builtin_shufflevector(X, X, 0, 1) * __builtin_shufflevector(Y, Y, 1, 0) + magic;
     const uint32_t m00 = __float_as_uint(Y.x * Y.y + 8388608.f);
@@ -143,6 +144,10 @@ __device__ __forceinline__ Weights bilinear_weights(float x, float y, float floo
     w.wl = __builtin_amdgcn_perm(m10, m00, 0x05040100u);
     w.wr = __builtin_amdgcn_perm(m11, m01, 0x05040100u);
     return w;
+}
+
+__device__ __forceinline__ Weights bilinear_weights(float x, float y, float floor_x, float floor_y) {
+    return bilinear_weights(f32x2{x, y} - f32x2{floor_x, floor_y});
 }
 
 // Eight consecutive bytes starting at byte offset `off` of a plane whose base is dword aligned.
@@ -503,8 +508,15 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         float backx = 0.f, backy = 0.f; // half of the last step, taken back when the steps alternate
         // One step: reads the previous step (qx, qy), leaves its own in (dx, dy).  Returns 0 to go on
         // with the same rows, 1 when the level is finished, 2 when the window corner has moved.
+        // frac = (nx - flx, ny - fly) travels from step to step: it is the next step's weight input, and it
+        // doubles as the "has the window corner moved?" test.  n - floor_old lies in [0, 1) exactly when
+        // floor(n) is still floor_old, except that a difference just below 1 may round up to 1; that rare
+        // case takes the slow path, finds the corner unchanged and goes on with the rounded value, which
+        // is what OpenCV's own subtraction yields.  For floats, 0 <= f < 1 is one unsigned compare of the
+        // bit pattern against that of 1.0f (negative values have the top bit set).
+        f32x2 frac = f32x2{nx, ny} - f32x2{flx, fly};
         auto gn_step = [&](const float qx, const float qy, float &dx, float &dy) __attribute__((always_inline)) -> int {
-            w = bilinear_weights(nx, ny, flx, fly);
+            w = bilinear_weights(frac);
             int dsum[RUN];
             sample_sums(cols, w, Ineg, dsum);
             const Packed7 dp = pack7_descale9(dsum); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
@@ -516,7 +528,9 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
             // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
             const float step_sq = dx * dx + dy * dy;
-            if (step_sq <= a.eps_lo || (step_sq < a.eps_hi && (double)dx * dx + (double)dy * dy <= a.eps_sq)) return 1;
+            if (step_sq < a.eps_hi) {
+                if (step_sq <= a.eps_lo || (double)dx * dx + (double)dy * dy <= a.eps_sq) return 1;
+            }
             // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
             // so "<= 0.01f" is the same predicate without leaving single precision
             if (j > 0 && fabsf(dx + qx) <= 0.01f && fabsf(dy + qy) <= 0.01f) {
@@ -524,7 +538,10 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
                 return 1;
             }
             if (++j >= a.max_count) return 1;
+            frac = f32x2{nx, ny} - f32x2{flx, fly};
+            if (__float_as_uint(frac.x) < 0x3F800000u && __float_as_uint(frac.y) < 0x3F800000u) return 0;
             flx = floorf(nx); fly = floorf(ny);
+            frac = f32x2{nx, ny} - f32x2{flx, fly};
             int kx, ky;
             scalar_xy((int)flx, (int)fly, kx, ky);
             if (kx != inx || ky != iny) { // new corner: bounds test and fetch in the outer loop
