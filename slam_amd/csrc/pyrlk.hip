@@ -250,7 +250,7 @@ __device__ __forceinline__ void sample_sums(const Cols &k, const Weights &w, int
         "s_nop 2"
         : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6)
         : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
-          "v"(w.wl), "v"(w.wr), "v"(acc0));
+          "v"(w.wl), "v"(w.wr), "s"(acc0)); // the shared start value rides in a scalar register
     d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = d4; d[5] = d5; d[6] = d6;
 }
 template <int SHIFT>
@@ -533,7 +533,11 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             }
             // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
             // so "<= 0.01f" is the same predicate without leaving single precision
-            if (j > 0 && fabsf(dx + qx) <= 0.01f && fabsf(dy + qy) <= 0.01f) {
+            // (before a level's first step the "previous step" is a huge value, so the test fails there
+            // without asking for j > 0; the steps are finite, so the maximum of the two magnitudes
+            // decides both comparisons at once)
+            const f32x2 back = f32x2{dx, dy} + f32x2{qx, qy};
+            if (fmaxf(fabsf(back.x), fabsf(back.y)) <= 0.01f) {
                 backx = dx * 0.5f; backy = dy * 0.5f;
                 return 1;
             }
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         // The step before the current one lives in (p1x, p1y) whenever the inner loop is entered; the
         // loop is unrolled twice with the two register pairs changing roles, so that no step copies
         // its result into "previous".
-        float p0x, p0y, p1x = 0.f, p1y = 0.f;
+        float p0x, p0y, p1x = 1e30f, p1y = 1e30f;
         if (a.max_count > 0) {
             for (;;) {
                 if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
