@@ -122,6 +122,7 @@ struct Weights {
     uint32_t wl, wr;
 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool NEGATED = false>
 __device__ __forceinline__ Weights bilinear_weights(f32x2 frac) {
     // frac = (a, b) = (x - floor(x), y - floor(y)) as OpenCV forms them;
     // iw00 = cvRound((1-a)*(1-b)*2^14), iw01 = cvRound(a*(1-b)*2^14), iw10 = cvRound((1-a)*b*2^14).
@@ -130,24 +131,33 @@ __device__ __forceinline__ Weights bilinear_weights(f32x2 frac) {
     // nearest-even integer and leaves it in the low mantissa bits.  Written on float pairs so that the
     // compiler emits packed instructions: X = (a, b 2^14), Y = (1 - a, (1 - b) 2^14), and one
     // v_pk_mul_f32 with crossed halves yields (a * Y.y, X.y * (1 - a)).
-    const f32x2 scale = {1.f, 16384.f}, magic = {8388608.f, 8388608.f};
+    // NEGATED yields the four weights with their signs flipped at the same cost: the product is subtracted
+    // from 1.5 * 2^23 (floats in [2^23, 2^24) are the integers, and ties-to-even is symmetric), which leaves
+    // -iw in the low 16 mantissa bits.
+    const f32x2 scale = {1.f, 16384.f};
+    const float M = NEGATED ? 12582912.f : 8388608.f;
+    const uint32_t MBITS = NEGATED ? 0x4B400000u : 0x4B000000u;
+    const f32x2 magic = {M, M};
     const f32x2 X = frac * scale;
     const f32x2 Y = scale - X;
-    const f32x2 cross = __builtin_shufflevector(X, X, 0, 1) * __builtin_shufflevector(Y, Y, 1, 0) + magic;
-    const uint32_t m00 = __float_as_uint(Y.x * Y.y + 8388608.f);
+    const f32x2 prod = __builtin_shufflevector(X, X, 0, 1) * __builtin_shufflevector(Y, Y, 1, 0);
+    const f32x2 cross = NEGATED ? magic - prod : prod + magic;
+    const float p00 = Y.x * Y.y;
+    const uint32_t m00 = __float_as_uint(NEGATED ? M - p00 : p00 + M);
     const uint32_t m01 = __float_as_uint(cross.x), m10 = __float_as_uint(cross.y);
-    // 16384 - iw00 - iw01 - iw10 in the low 16 bits (the 0x4B000000 exponent fields cancel mod 2^32)
+    // +-(16384 - iw00 - iw01 - iw10) in the low 16 bits (the exponent fields cancel mod 2^32)
     uint32_t m3; // m00 + m01 + m10 in one instruction; the s_nop covers the packed result read by asm
     asm("s_nop 0\n\tv_add3_u32 %0, %1, %2, %3" : "=v"(m3) : "v"(m00), "v"(m01), "v"(m10));
-    const uint32_t m11 = (16384u + 3u * 0x4B000000u) - m3;
+    const uint32_t m11 = (NEGATED ? 3u * MBITS - 16384u : 16384u + 3u * MBITS) - m3;
     Weights w;
     w.wl = __builtin_amdgcn_perm(m10, m00, 0x05040100u);
     w.wr = __builtin_amdgcn_perm(m11, m01, 0x05040100u);
     return w;
 }
 
+template <bool NEGATED = false>
 __device__ __forceinline__ Weights bilinear_weights(float x, float y, float floor_x, float floor_y) {
-    return bilinear_weights(f32x2{x, y} - f32x2{floor_x, floor_y});
+    return bilinear_weights<NEGATED>(f32x2{x, y} - f32x2{floor_x, floor_y});
 }
 
 // Eight consecutive bytes starting at byte offset `off` of a plane whose base is dword aligned.
@@ -386,6 +396,8 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     const float halfWin = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
 
+    uint32_t k255;
+    asm("v_mov_b32 %0, 0xff" : "=v"(k255));
     float ox = 0.f, oy = 0.f; // nextPts[i]
     int status = 1;
     float errv = 0.f;
@@ -430,7 +442,10 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         Raw12 jt = fetch_run8(Jbase, je), jb = fetch_run8(Jbase, je + pitch);
 
         // ---- template: image rows ipy+r, +1 and Scharr rows ipy+r, +1, columns ipx+cx .. +7 -----
-        int Ineg[RUN];     // 256 - 512 * I: accumulator start of the mismatch samples
+        // 512 * I + 255: accumulator start of the mismatch samples, which are summed with NEGATED weights:
+        // (512 I + 255 - sum) >> 9 = I - CV_DESCALE(sum, 9), the mismatch with its sign flipped, and the
+        // start value is one v_and_or_b32 away from the template's own sum
+        int Ineg[RUN];
         Packed7 ixp, iyp;  // the template's derivatives as int16 pairs
         {
             const uint32_t e0 = lane_off + (uint32_t)(ipy * pitch + ipx);
@@ -442,10 +457,11 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
             for (int k = 0; k <= RUN; k++) { d0[k] = dt[k]; d1[k] = db[k]; }
             {
-                int Iv[RUN];
-                sample_run<9>(col_pairs(t, b), w, 256, Iv);
+                int Is[RUN]; // 512 * I + remainder
+                sample_sums(col_pairs(t, b), w, 256, Is);
 #pragma unroll
-                for (int i = 0; i < RUN; i++) Ineg[i] = 256 - (Iv[i] << 9);
+                for (int i = 0; i < RUN; i++) // (Is[i] & ~511) | 255 (no literals in this encoding: mask in a scalar, 255 in a vector register)
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(Ineg[i]) : "v"(Is[i]), "s"(0xFFFFFE00u), "v"(k255));
             }
             // column pairs (top, bottom) of dx and of dy; each serves two neighbouring samples
             Cols cxp, cyp;
@@ -488,7 +504,8 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         D = 1.f / D;
         // FLT_SCALE is a power of two, so scaling b1, b2 by it (as OpenCV does before forming the step)
         // commutes with every rounding below and can be applied to D once per level instead
-        const float Ds = D * FLT_SCALE;
+        // (negative: the mismatch sums come with their sign flipped)
+        const float Ds = -(D * FLT_SCALE);
 
         // ---- Gauss-Newton iterations -----------------------------------------------------------
         // The rows fetched for one step serve the following steps as long as the window's integer
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         // bit pattern against that of 1.0f (negative values have the top bit set).
         f32x2 frac = f32x2{nx, ny} - f32x2{flx, fly};
         auto gn_step = [&](const float qx, const float qy, float &dx, float &dy) __attribute__((always_inline)) -> int {
-            w = bilinear_weights(frac);
+            w = bilinear_weights<true>(frac);
             int dsum[RUN];
             sample_sums(cols, w, Ineg, dsum);
             const Packed7 dp = pack7_descale9(dsum); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
@@ -599,7 +616,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                 status = 0;
             } else {
-                w = bilinear_weights(fx, fy, (float)inx, (float)iny);
+                w = bilinear_weights<true>(fx, fy, (float)inx, (float)iny);
                 if (inx != have_x || iny != have_y) {
                     const uint32_t e0 = lane_off + (uint32_t)(iny * pitch + inx);
                     cols = col_pairs(load_run8(Jbase, e0), load_run8(Jbase, e0 + pitch));
