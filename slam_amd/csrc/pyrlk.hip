@@ -304,6 +304,41 @@ __device__ __forceinline__ Packed7 pack7_high(const int (&d)[7]) {
     r.p[3] = (uint32_t)d[6] >> 16;
     return r;
 }
+// sample_sums followed by pack7_descale9 as one block.  A dot's result may be read by another kind of
+// instruction three wait states later; here the packing instructions are ordered so that every one of
+// them comes at least that long after the dot it depends on, and the block needs no idle wait at all
+// (the last-but-one sum is complete at the 13th dot and first read by the third permute).
+__device__ __forceinline__ Packed7 sample_pack(const Cols &k, const Weights &w, const int (&acc0)[7]) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6;
+    asm("v_dot2_i32_i16 %0, %7, %15, %17\n\t"
+        "v_dot2_i32_i16 %1, %8, %15, %18\n\t"
+        "v_dot2_i32_i16 %2, %9, %15, %19\n\t"
+        "v_dot2_i32_i16 %3, %10, %15, %20\n\t"
+        "v_dot2_i32_i16 %4, %11, %15, %21\n\t"
+        "v_dot2_i32_i16 %5, %12, %15, %22\n\t"
+        "v_dot2_i32_i16 %6, %13, %15, %23\n\t"
+        "v_dot2_i32_i16 %0, %8, %16, %0\n\t"
+        "v_dot2_i32_i16 %1, %9, %16, %1\n\t"
+        "v_dot2_i32_i16 %2, %10, %16, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %16, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %16, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %16, %5\n\t"
+        "v_dot2_i32_i16 %6, %14, %16, %6\n\t"
+        "v_perm_b32 %0, %1, %0, %24\n\t"
+        "v_perm_b32 %2, %3, %2, %24\n\t"
+        "v_perm_b32 %4, %5, %4, %24\n\t"
+        "v_pk_ashrrev_i16 %0, 1, %0 op_sel_hi:[0,1]\n\t"
+        "v_pk_ashrrev_i16 %2, 1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_ashrrev_i16 %4, 1, %4 op_sel_hi:[0,1]\n\t"
+        "v_bfe_u32 %6, %6, 9, 16"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6)
+        : "v"(k.c[0]), "v"(k.c[1]), "v"(k.c[2]), "v"(k.c[3]), "v"(k.c[4]), "v"(k.c[5]), "v"(k.c[6]), "v"(k.c[7]),
+          "v"(w.wl), "v"(w.wr), "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]),
+          "v"(acc0[6]), "s"(0x06050201u));
+    Packed7 r;
+    r.p[0] = t0; r.p[1] = t2; r.p[2] = t4; r.p[3] = t6;
+    return r;
+}
 // (sum of x[i] * y[i], sum of x[i] * z[i]) over the seven values, exact in int32
 struct Dot2 {
     int xy, xz;
@@ -534,9 +569,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         f32x2 frac = f32x2{nx, ny} - f32x2{flx, fly};
         auto gn_step = [&](const float qx, const float qy, float &dx, float &dy) __attribute__((always_inline)) -> int {
             w = bilinear_weights<true>(frac);
-            int dsum[RUN];
-            sample_sums(cols, w, Ineg, dsum);
-            const Packed7 dp = pack7_descale9(dsum); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
+            const Packed7 dp = sample_pack(cols, w, Ineg); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
             const Dot2 bb = dot7x2(dp, ixp, iyp);
             const Sum2 bs = wave_sum2(bb.xy, bb.xz);
             dx = (A12 * bs.b - A22 * bs.a) * Ds;
