@@ -133,6 +133,8 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // the tracker's bilinear sums then carry CV_DESCALE(sum, 14) in their upper 16 bits, where one byte
 // permute packs two of them.  ktlvo_download_scharr divides by four again.
 // Only the interior of the plane is written; its frame stays zero (copyMakeBorder BORDER_CONSTANT).
+// STREAM: the planes are written with non-temporal stores (see the launch site for when).
+template <bool STREAM>
 __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, SlotList list, int n_levels) {
     const int level = blockIdx.y;
     if (level >= n_levels) return;
@@ -178,10 +180,13 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
     const gword o = (gword)L.dorigin + (ptrdiff_t)y * L.pitch + x0;
     if (x0 + 7 < L.w) {
         typedef __attribute__((address_space(1))) u32x4 *gquad;
-        // non-temporal: the planes of a batch are far larger than the caches and are not read again before
-        // the LK launch, so the stores should not allocate there (a quarter off the kernel's time)
-        __builtin_nontemporal_store(u32x4{out[0], out[1], out[2], out[3]}, &((gquad)o)[0]);
-        __builtin_nontemporal_store(u32x4{out[4], out[5], out[6], out[7]}, &((gquad)o)[1]);
+        if (STREAM) {
+            __builtin_nontemporal_store(u32x4{out[0], out[1], out[2], out[3]}, &((gquad)o)[0]);
+            __builtin_nontemporal_store(u32x4{out[4], out[5], out[6], out[7]}, &((gquad)o)[1]);
+        } else {
+            ((gquad)o)[0] = u32x4{out[0], out[1], out[2], out[3]};
+            ((gquad)o)[1] = u32x4{out[4], out[5], out[6], out[7]};
+        }
     } else {
         for (int k = 0; k < 8 && x0 + k < L.w; k++) o[k] = out[k];
     }
@@ -283,7 +288,16 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
             ProfScope ps2(ctx, KTLVO_K_SCHARR);
             const int octets0 = ((ctx->lw[0] + 7) / 8) * ctx->lh[0];
             dim3 grid((octets0 + 255) / 256, top + 1, list.n);
-            hipLaunchKernelGGL(scharr_planes, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, top + 1);
+            // Planes of a batch far larger than the 256 MiB of last-level cache are not read again before
+            // they have been evicted, so their stores should not allocate there (a quarter off the kernel's
+            // time for the 256 KITTI-sized frames of a benchmark step); a smaller batch, down to the two
+            // frames of the per-frame path, is read by the LK launch that follows while still cached.
+            size_t plane_bytes = 0;
+            for (int l = 0; l <= top; l++) plane_bytes += (size_t)ctx->lw[l] * ctx->lh[l] * 4;
+            if (plane_bytes * list.n >= ((size_t)512 << 20))
+                hipLaunchKernelGGL(scharr_planes<true>, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, top + 1);
+            else
+                hipLaunchKernelGGL(scharr_planes<false>, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, top + 1);
             KTLVO_HIP(ctx, hipGetLastError());
         }
     }
