@@ -10,6 +10,7 @@ For narrower gathers the factor is uncalibrated: the doubled value is an upper e
 import collections
 import csv
 import json
+import re
 import sys
 
 
@@ -18,11 +19,12 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("ktlvo::", "")
+            # "void ktlvo::pyrlk_track_w21<4>(ktlvo::LkArgs)" -> "pyrlk_track_w21": instantiations of one kernel pool
+            k = re.sub(r"<[^<>]*>", "", r["Kernel_Name"].split("(")[0]).replace("ktlvo::", "").replace("void ", "").strip()
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, d in agg.items():
-        if k.startswith(("void at::", "__amd")):
+        if k.startswith(("at::", "void at::", "__amd")):
             continue
         e = {c: sum(v) / len(v) for c, v in d.items()}
         e["launches_sampled"] = max(len(v) for v in d.values())

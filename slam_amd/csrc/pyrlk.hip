@@ -394,7 +394,11 @@ __device__ __forceinline__ void scalar_xy(int vx, int vy, int &sx, int &sy) {
 #ifndef LK_WPB
 #define LK_WPB 1
 #endif
+// MAXL >= 0 fixes the top level at compile time, and the level loop is then unrolled (level-dependent scalars
+// become constants; 0.5 % faster at five times the code); MAXL < 0 takes it from the arguments.
+template <int MAXL>
 __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void pyrlk_track_w21(LkArgs a) {
+    const int max_level = MAXL >= 0 ? MAXL : a.max_level;
     const int lane = threadIdx.x & 63;
     const int wave = uniform((int)(threadIdx.x >> 6));
     // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each with its
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     int status = 1;
     float errv = 0.f;
 
-    for (int level = a.max_level; level >= 0; --level) {
+#pragma unroll
+    for (int level = max_level; level >= 0; --level) {
         const LevelDesc I = SP.lv[level];
         const LevelDesc J = SN.lv[level];
         const int pitch = I.pitch; // both slots share the level geometry
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
 
         const float sc = __int_as_float((127 - level) << 23); // (float)(1./(1 << level))
         float px = ppx * sc, py = ppy * sc;
-        if (level == a.max_level) { ox = px; oy = py; }
+        if (level == max_level) { ox = px; oy = py; }
         else { ox = ox * 2.f; oy = oy * 2.f; }
 
         px -= halfWin; py -= halfWin;
@@ -728,7 +733,9 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     a.blocks_per_pair = (n_per_pair + LK_WPB - 1) / LK_WPB;
     dim3 grid((unsigned)(n_pairs * a.blocks_per_pair));
     ProfScope ps(ctx, KTLVO_K_PYRLK);
-    hipLaunchKernelGGL(pyrlk_track_w21, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
+    // the reference's maxLevel (featureTracking.cpp:208) gets the unrolled kernel
+    if (max_level == 4) hipLaunchKernelGGL(pyrlk_track_w21<4>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(pyrlk_track_w21<-1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }
