@@ -99,6 +99,27 @@ def test_pyramid_batched_build_equals_single(make_ctx):
             assert np.array_equal(ctx.download_level(s, l), ctx2.download_level(0, l))
 
 
+def test_scharr_large_batch_store_path(make_ctx, oracle):
+    """A batch whose Scharr planes exceed 512 MiB is written with non-temporal stores (the benchmark
+    step's path); the planes must be the same bits as the small-batch path gives and the oracle derives."""
+    W, H, n = 1241, 376, 224                     # 224 x 2.37 MiB of planes = 531 MiB
+    ctx = make_ctx(width=W, height=H, num_slots=n)
+    imgs = [synth.texture_image(W, H, seed=40 + s, noise=True) for s in range(3)]
+    for s in range(n):
+        ctx.upload_image(s, imgs[s % 3])
+    ctx.build_pyramids(list(range(n)))
+    ctx1 = make_ctx(width=W, height=H, num_slots=1)
+    for s in (0, 1, 2, n // 2, n - 1):
+        ctx1.upload_image(0, imgs[s % 3])
+        ctx1.build_pyramid(0)
+        po = oracle.Pyramid(imgs[s % 3], 4, 21)
+        for l in range(ctx.pyramid_levels(s) + 1):
+            lv = po.level(l)
+            big = ctx.download_scharr(s, l, lv.shape[1], lv.shape[0])
+            assert np.array_equal(big, ctx1.download_scharr(0, l, lv.shape[1], lv.shape[0])), (s, l)
+            assert np.array_equal(big, po.deriv(l)), (s, l)
+
+
 # ---------------------------------------------------------------- LK --------------------------
 @pytest.mark.parametrize("shift", [(0.3, -0.2), (3.3, -1.7), (-9.5, 6.25)])
 def test_lk_matches_oracle_and_truth(make_ctx, oracle, shift):
