@@ -91,6 +91,11 @@ _lib.orc_rodrigues_m2v.argtypes = [_f64p, _f64p]
 _lib.orc_rodrigues_m2v.restype = None
 _lib.orc_p3p.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p]
 _lib.orc_solve_p3p4.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p]
+_lib.orc_gao_quartic.argtypes = [C.c_double] * 5 + [_f64p]
+_lib.orc_gao_quartic.restype = None
+_lib.orc_roots4.argtypes = [_f64p, _f64p]
+_lib.orc_p3p_set_polish.argtypes = [C.c_int]
+_lib.orc_p3p_set_polish.restype = None
 _lib.orc_project_score.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, C.c_float, C.c_void_p, C.c_void_p]
 _lib.orc_solve_pnp_ransac.argtypes = [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_float, C.c_double, _f64p, _f64p,
                                       C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
@@ -280,6 +285,22 @@ def solve_p3p4(X, uv, K):
                              np.ascontiguousarray(uv, np.float64).reshape(8), np.ascontiguousarray(K, np.float64), R,
                              t)
     return bool(ok), R.reshape(3, 3), t
+
+
+def gao_quartic(a, b, p, q, r):
+    c = np.zeros(5, np.float64)
+    _lib.orc_gao_quartic(a, b, p, q, r, c)
+    return c
+
+
+def p3p_set_polish(newton_steps):
+    _lib.orc_p3p_set_polish(int(newton_steps))
+
+
+def roots4(coef):
+    x = np.zeros(4, np.float64)
+    n = _lib.orc_roots4(np.ascontiguousarray(coef, np.float64), x)
+    return x[:n]
 
 
 def project_score(X3, x2, Rt, K, thr_sq):

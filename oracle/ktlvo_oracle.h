@@ -88,12 +88,22 @@ int orc_depth_gate(const float *last_left, const float *last_right, int n, doubl
 void orc_rodrigues_v2m(const double r[3], double R[9]);
 void orc_rodrigues_m2v(const double R[9], double r[3]);
 
-/* P3P on 3 correspondences: up to 4 (R row-major 9, t 3) solutions. K = fx,fy,cx,cy. */
+/* P3P on 3 correspondences (Gao et al., ktlvo_oracle_p3p.cpp): up to 4 (R row-major 9, t 3)
+ * solutions. K = fx,fy,cx,cy. */
 int orc_p3p(const double X[9], const double uv[6], const double K[4], double R[36],
             double t[12]);
 /* solvePnP(..., SOLVEPNP_P3P) on exactly 4 points (4th disambiguates). returns 1/0. */
 int orc_solve_p3p4(const double X[12], const double uv[8], const double K[4], double R[9],
                    double t[3]);
+
+/* Test hooks of the P3P: the Gao quartic's coefficients (highest power first) for
+ * a = |P1P2|^2/|P0P1|^2, b = |P0P2|^2/|P0P1|^2, p, q, r = twice the cosines between the bearings
+ * (1,2), (0,2), (0,1); and the closed-form real roots of a quartic (count returned). */
+void orc_gao_quartic(double a, double b, double p, double q, double r, double coef[5]);
+int orc_roots4(const double coef[5], double roots[4]);
+/* Newton steps applied to each root of the Gao quartic before it is used (process-wide; default 0 =
+ * the closed-form roots as they are, as in OpenCV 3.x). */
+void orc_p3p_set_polish(int newton_steps);
 
 /* PnPRansacCallback::computeError + findInliers for one model: projectPoints in double,
  * float projections, float squared error, err <= thr_sq.  Rt = R(9 row-major) then t(3).

@@ -9,8 +9,7 @@
  *   Rodrigues, as reached from visualOdometry.cpp:177-217 (parameters :122-127);
  *   UnprojectStereo :153-167, pose chaining :311-326;
  *   stereoImageCallback featureTracking.cpp:339-666.
- * The minimal solver is a three-point Grunert-type P3P written for this oracle (OpenCV's is
- * the Gao et al. solver; both return the same up-to-four poses of the same three points).
+ * The minimal solver (orc_p3p, orc_solve_p3p4) is the Gao et al. P3P in ktlvo_oracle_p3p.cpp.
  */
 #include "ktlvo_oracle.h"
 
@@ -59,215 +58,6 @@ extern "C" void orc_rodrigues_m2v(const double R[9], double r[3]) {
         x *= vth; y *= vth; z *= vth;
     }
     r[0] = x; r[1] = y; r[2] = z;
-}
-
-namespace {
-
-/* ---- polynomial helpers ------------------------------------------------------------------ */
-int solve_quadratic(double a, double b, double c, double *x) {
-    if (a == 0) { if (b == 0) return 0; x[0] = -c / b; return 1; }
-    double d = b * b - 4 * a * c;
-    if (d < 0) return 0;
-    double sd = std::sqrt(d);
-    double q = -0.5 * (b + (b >= 0 ? sd : -sd));
-    if (q == 0) { x[0] = 0; x[1] = 0; return 2; }
-    x[0] = q / a; x[1] = c / q;
-    return 2;
-}
-
-/* one real root of x^3 + a x^2 + b x + c (the largest) */
-double cubic_largest_root(double a, double b, double c) {
-    double a3 = a / 3.0;
-    double p = b - a * a3, q = 2 * a3 * a3 * a3 - a3 * b + c; /* t^3 + p t + q, x = t - a/3 */
-    double disc = q * q / 4 + p * p * p / 27;
-    double t;
-    if (disc > 0) {
-        double sd = std::sqrt(disc);
-        t = std::cbrt(-q / 2 + sd) + std::cbrt(-q / 2 - sd);
-    } else if (p == 0) {
-        t = std::cbrt(-q);
-    } else {
-        double m = 2 * std::sqrt(-p / 3);
-        double arg = 3 * q / (p * m);
-        arg = std::max(-1.0, std::min(1.0, arg));
-        t = m * std::cos(std::acos(arg) / 3); /* k = 0 branch is the largest */
-    }
-    double x = t - a3;
-    for (int i = 0; i < 3; i++) { /* Newton polish */
-        double f = ((x + a) * x + b) * x + c, df = (3 * x + 2 * a) * x + b;
-        if (df == 0) break;
-        x -= f / df;
-    }
-    return x;
-}
-
-int solve_quartic(const double k[5] /* k0 + k1 x + ... + k4 x^4 */, double *roots) {
-    if (std::fabs(k[4]) < 1e-14 * (std::fabs(k[3]) + std::fabs(k[2]) + std::fabs(k[1]) + std::fabs(k[0]))) {
-        /* degenerate: not expected for P3P in general position */
-        return 0;
-    }
-    double a = k[3] / k[4], b = k[2] / k[4], c = k[1] / k[4], d = k[0] / k[4];
-    double a2 = a * a;
-    double p = b - 3 * a2 / 8, q = c - a * b / 2 + a2 * a / 8;
-    double r = d - a * c / 4 + a2 * b / 16 - 3 * a2 * a2 / 256;
-    double y[4];
-    int n = 0;
-    if (std::fabs(q) < 1e-14 * (1 + std::fabs(p) + std::fabs(r))) {
-        double t[2];
-        int nt = solve_quadratic(1, p, r, t);
-        for (int i = 0; i < nt; i++)
-            if (t[i] >= 0) { double s = std::sqrt(t[i]); y[n++] = s; y[n++] = -s; }
-    } else {
-        /* m solves 8m^3 + 8p m^2 + (2p^2 - 8r) m - q^2 = 0, m > 0 */
-        double m = cubic_largest_root(p, (p * p - 4 * r) / 4, -q * q / 8);
-        if (m <= 0) return 0;
-        double s2m = std::sqrt(2 * m);
-        double t[2];
-        int nt = solve_quadratic(1, -s2m, p / 2 + m + q / (2 * s2m), t);
-        for (int i = 0; i < nt; i++) y[n++] = t[i];
-        nt = solve_quadratic(1, s2m, p / 2 + m - q / (2 * s2m), t);
-        for (int i = 0; i < nt; i++) y[n++] = t[i];
-    }
-    for (int i = 0; i < n; i++) {
-        double x = y[i] - a / 4;
-        for (int it = 0; it < 2; it++) { /* Newton polish on the original quartic */
-            double f = (((k[4] * x + k[3]) * x + k[2]) * x + k[1]) * x + k[0];
-            double df = ((4 * k[4] * x + 3 * k[3]) * x + 2 * k[2]) * x + k[1];
-            if (df == 0) break;
-            x -= f / df;
-        }
-        roots[i] = x;
-    }
-    return n;
-}
-
-inline void cross3(const double a[3], const double b[3], double o[3]) {
-    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
-}
-inline double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-inline bool normalize3(double a[3]) {
-    double n = std::sqrt(dot3(a, a));
-    if (n < 1e-300) return false;
-    a[0] /= n; a[1] /= n; a[2] /= n;
-    return true;
-}
-
-/* orthonormal triad (columns e1,e2,e3) from three points */
-bool triad(const double P1[3], const double P2[3], const double P3[3], double E[9]) {
-    double e1[3] = {P2[0] - P1[0], P2[1] - P1[1], P2[2] - P1[2]};
-    double w[3] = {P3[0] - P1[0], P3[1] - P1[1], P3[2] - P1[2]};
-    double e3[3], e2[3];
-    if (!normalize3(e1)) return false;
-    cross3(e1, w, e3);
-    if (!normalize3(e3)) return false;
-    cross3(e3, e1, e2);
-    for (int i = 0; i < 3; i++) { E[3 * i] = e1[i]; E[3 * i + 1] = e2[i]; E[3 * i + 2] = e3[i]; }
-    return true;
-}
-
-}  // namespace
-
-extern "C" int orc_p3p(const double X[9], const double uv[6], const double K[4], double Rout[36],
-                       double tout[12]) {
-    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
-    double f[3][3];
-    for (int i = 0; i < 3; i++) {
-        f[i][0] = (uv[2 * i] - cx) / fx; f[i][1] = (uv[2 * i + 1] - cy) / fy; f[i][2] = 1.0;
-        normalize3(f[i]);
-    }
-    const double *P1 = X, *P2 = X + 3, *P3 = X + 6;
-    auto dist2 = [](const double *a, const double *b) {
-        double d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
-        return d0 * d0 + d1 * d1 + d2 * d2;
-    };
-    const double a2 = dist2(P2, P3), b2 = dist2(P1, P3), c2 = dist2(P1, P2);
-    if (a2 < 1e-20 || b2 < 1e-20 || c2 < 1e-20) return 0;
-    const double ca = dot3(f[1], f[2]), cb = dot3(f[0], f[2]), cg = dot3(f[0], f[1]);
-    double Ew[9];
-    if (!triad(P1, P2, P3, Ew)) return 0;
-
-    /* s2 = u s1, s3 = v s1.  A(v) = 1 + v^2 - 2 v cb.
-     * u = N(v)/D(v), N = (a2-c2) A + b2 (1 - v^2), D = 2 b2 (cg - v ca)
-     * quartic: b2 (D^2 + N^2 - 2 cg N D) - c2 A D^2 = 0 */
-    const double A[3] = {1, -2 * cb, 1};
-    const double N[3] = {(a2 - c2) * A[0] + b2, (a2 - c2) * A[1], (a2 - c2) * A[2] - b2};
-    const double D[2] = {2 * b2 * cg, -2 * b2 * ca};
-    double DD[3] = {D[0] * D[0], 2 * D[0] * D[1], D[1] * D[1]};
-    double NN[5] = {0, 0, 0, 0, 0}, ND[4] = {0, 0, 0, 0}, ADD[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) { NN[i + j] += N[i] * N[j]; ADD[i + j] += A[i] * DD[j]; }
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 2; j++) ND[i + j] += N[i] * D[j];
-    double Q[5];
-    for (int i = 0; i < 5; i++) {
-        double dd = i < 3 ? DD[i] : 0, nd = i < 4 ? ND[i] : 0;
-        Q[i] = b2 * (dd + NN[i] - 2 * cg * nd) - c2 * ADD[i];
-    }
-    /* scale for conditioning */
-    double qs = 0;
-    for (int i = 0; i < 5; i++) qs = std::max(qs, std::fabs(Q[i]));
-    if (qs == 0) return 0;
-    for (int i = 0; i < 5; i++) Q[i] /= qs;
-
-    double roots[4];
-    int nr = solve_quartic(Q, roots);
-    int ns = 0;
-    for (int ri = 0; ri < nr && ns < 4; ri++) {
-        double v = roots[ri];
-        if (!(v > 0)) continue;
-        double Dv = D[0] + D[1] * v;
-        if (std::fabs(Dv) < 1e-12 * b2) continue;
-        double Nv = N[0] + (N[1] + N[2] * v) * v;
-        double u = Nv / Dv;
-        if (!(u > 0)) continue;
-        double Av = A[0] + (A[1] + A[2] * v) * v;
-        if (!(Av > 0)) continue;
-        double s1 = std::sqrt(b2 / Av), s2 = u * s1, s3 = v * s1;
-        /* duplicate roots give duplicate poses; drop near-identical ones */
-        double C1[3] = {s1 * f[0][0], s1 * f[0][1], s1 * f[0][2]};
-        double C2[3] = {s2 * f[1][0], s2 * f[1][1], s2 * f[1][2]};
-        double C3[3] = {s3 * f[2][0], s3 * f[2][1], s3 * f[2][2]};
-        double Ec[9];
-        if (!triad(C1, C2, C3, Ec)) continue;
-        double *R = Rout + 9 * ns, *t = tout + 3 * ns;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                double s = 0;
-                for (int k = 0; k < 3; k++) s += Ec[3 * i + k] * Ew[3 * j + k];
-                R[3 * i + j] = s;
-            }
-        for (int i = 0; i < 3; i++) t[i] = C1[i] - (R[3 * i] * P1[0] + R[3 * i + 1] * P1[1] + R[3 * i + 2] * P1[2]);
-        bool dup = false;
-        for (int p = 0; p < ns && !dup; p++) {
-            double e = 0;
-            for (int i = 0; i < 9; i++) e = std::max(e, std::fabs(Rout[9 * p + i] - R[i]));
-            for (int i = 0; i < 3; i++) e = std::max(e, std::fabs(tout[3 * p + i] - t[i]) / (1 + std::fabs(t[i])));
-            dup = e < 1e-9;
-        }
-        if (!dup) ns++;
-    }
-    return ns;
-}
-
-extern "C" int orc_solve_p3p4(const double X[12], const double uv[8], const double K[4], double R[9],
-                              double t[3]) {
-    double Rs[36], ts[12];
-    int n = orc_p3p(X, uv, K, Rs, ts);
-    if (n == 0) return 0;
-    int best = 0;
-    double min_reproj = 0;
-    for (int i = 0; i < n; i++) {
-        const double *Ri = Rs + 9 * i, *ti = ts + 3 * i;
-        double Xp = Ri[0] * X[9] + Ri[1] * X[10] + Ri[2] * X[11] + ti[0];
-        double Yp = Ri[3] * X[9] + Ri[4] * X[10] + Ri[5] * X[11] + ti[1];
-        double Zp = Ri[6] * X[9] + Ri[7] * X[10] + Ri[8] * X[11] + ti[2];
-        double mu = K[2] + K[0] * Xp / Zp, mv = K[3] + K[1] * Yp / Zp;
-        double reproj = (mu - uv[6]) * (mu - uv[6]) + (mv - uv[7]) * (mv - uv[7]);
-        if (i == 0 || min_reproj > reproj) { best = i; min_reproj = reproj; }
-    }
-    memcpy(R, Rs + 9 * best, 9 * sizeof(double));
-    memcpy(t, ts + 3 * best, 3 * sizeof(double));
-    return 1;
 }
 
 extern "C" int orc_project_score(const float *X3, const float *x2, int n, const double Rt[12],

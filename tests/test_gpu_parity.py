@@ -531,16 +531,24 @@ def test_ransac_score_large_batch(make_ctx, oracle):
 
 
 def test_solve_pnp_ransac_matches_oracle(make_ctx, oracle):
+    """Both hypothesis paths of the library (P3P on the host, P3P in a kernel) against the golden result of the
+    oracle's RANSAC, whose minimal solver is an independent Gao et al. P3P (oracle/ktlvo_oracle_p3p.cpp:
+    other unknowns, other quartic, closed-form roots, Horn alignment): same selected hypothesis (the golden
+    log lists every hypothesis' count), same inlier mask, pose within 1e-8 (two formulations of one pose in
+    double precision; observed 5e-14 on this fixture)."""
     g = np.load(os.path.join(GOLD, "ransac_400.npz"))
-    ctx = make_ctx()
-    r = ctx.solve_pnp_ransac(g["X3"], g["x2"])
-    assert r["ok"] and r["n_inliers"] == int(g["n_inliers"])
-    assert np.array_equal(r["mask"], g["mask"])
-    assert np.abs(r["rvec"] - g["rvec"]).max() < 1e-12 and np.abs(r["tvec"] - g["tvec"]).max() < 1e-12
-    r = ctx.solve_pnp_ransac(g["X3"][:3], g["x2"][:3])
-    assert not r["ok"]
-    r = ctx.solve_pnp_ransac(g["X3"][:0], g["x2"][:0])
-    assert not r["ok"]
+    live = oracle.solve_pnp_ransac(g["X3"], g["x2"], g["K"])
+    assert live["n_inliers"] == int(g["n_inliers"]) and np.array_equal(live["mask"], g["mask"])
+    for dev in (0, 1):
+        ctx = make_ctx(device_p3p=dev)
+        r = ctx.solve_pnp_ransac(g["X3"], g["x2"])
+        assert r["ok"] and r["n_inliers"] == int(g["n_inliers"]), dev
+        assert np.array_equal(r["mask"], g["mask"]), dev
+        assert np.abs(r["rvec"] - g["rvec"]).max() < 1e-8 and np.abs(r["tvec"] - g["tvec"]).max() < 1e-8, dev
+        r = ctx.solve_pnp_ransac(g["X3"][:3], g["x2"][:3])
+        assert not r["ok"]
+        r = ctx.solve_pnp_ransac(g["X3"][:0], g["x2"][:0])
+        assert not r["ok"]
 
 
 # ---------------------------------------------------------------- full benchmark sizes -----------
@@ -577,16 +585,12 @@ def test_full_size_frames(make_ctx, oracle, klib, size, ncorners, min_dist):
     assert np.median(np.abs(r - xy)[ok]) < 0.02
 
 
-def test_device_p3p_matches_host_p3p(make_ctx, oracle):
-    """Hypothesis generation on the GPU (one thread per P3P) against the host solver: same
-    algorithm, device libm, so poses agree to rounding and the selected model is the same."""
-    g = np.load(os.path.join(GOLD, "ransac_400.npz"))
-    host = make_ctx().solve_pnp_ransac(g["X3"], g["x2"])
-    dev = make_ctx(device_p3p=1).solve_pnp_ransac(g["X3"], g["x2"])
-    assert dev["ok"] and abs(dev["n_inliers"] - host["n_inliers"]) <= 1
-    assert np.abs(dev["rvec"] - host["rvec"]).max() < 1e-9 and np.abs(dev["tvec"] - host["tvec"]).max() < 1e-9
-    assert (dev["mask"] != host["mask"]).sum() <= 1
-    # max-size batch: 1024 hypotheses
+def test_pnp_ransac_1024_hypotheses_against_oracle(make_ctx, oracle):
+    """Maximum batch (1024 hypotheses, 3000 points): host-P3P and device-P3P paths against the oracle's
+    sequential RANSAC with its independent Gao P3P.  A handful of the 1024 hypotheses are resolved less
+    accurately by the oracle's closed-form roots than by the library's polished ones, so a count may
+    differ by a borderline point: inlier totals within 2, masks within 2 points, poses within 1e-6,
+    and all three within 2e-3 of the planted rotation."""
     rng = np.random.default_rng(5)
     X = np.stack([rng.uniform(-8, 8, 3000), rng.uniform(-2, 2, 3000), rng.uniform(4, 38, 3000)], 1).astype(np.float32)
     R = oracle.rodrigues_v2m(np.array([0.01, -0.02, 0.005]))
@@ -594,11 +598,14 @@ def test_device_p3p_matches_host_p3p(make_ctx, oracle):
     K = np.array([707.0912, 707.0912, 601.8873, 183.1104])
     uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
     uv = (uv + rng.normal(size=uv.shape) * 0.03).astype(np.float32)
-    a = make_ctx().solve_pnp_ransac(X, uv, max_iters=1024)
-    b = make_ctx(device_p3p=1).solve_pnp_ransac(X, uv, max_iters=1024)
-    assert a["ok"] and b["ok"] and abs(a["n_inliers"] - b["n_inliers"]) <= 2
-    assert np.abs(a["rvec"] - b["rvec"]).max() < 1e-8 and np.abs(a["tvec"] - b["tvec"]).max() < 1e-8
-    assert np.abs(b["rvec"] - np.array([0.01, -0.02, 0.005])).max() < 2e-3
+    o = oracle.solve_pnp_ransac(X, uv, K, max_iters=1024)
+    assert o["ok"]
+    for dev in (0, 1):
+        r = make_ctx(device_p3p=dev).solve_pnp_ransac(X, uv, max_iters=1024)
+        assert r["ok"] and abs(r["n_inliers"] - o["n_inliers"]) <= 2, (dev, r["n_inliers"], o["n_inliers"])
+        assert (r["mask"] != o["mask"]).sum() <= 2, dev
+        assert np.abs(r["rvec"] - o["rvec"]).max() < 1e-6 and np.abs(r["tvec"] - o["tvec"]).max() < 1e-6, dev
+        assert np.abs(r["rvec"] - np.array([0.01, -0.02, 0.005])).max() < 2e-3
 
 
 def test_profiling_mask_selects_kernels(make_ctx, klib):

@@ -1,0 +1,153 @@
+"""The library's minimal pose solver (slam_amd/csrc/p3p.hpp, built for the host by tests/cpp) against the
+oracle's independent Gao et al. P3P (oracle/ktlvo_oracle_p3p.cpp): different unknowns, different quartic,
+different root finder, different alignment.  CPU only.
+
+The reference reaches this code through cv::solvePnPRansac(..., SOLVEPNP_P3P), visualOdometry.cpp:122-127,
+206-208.  Parity unpinned: OpenCV 3.x is not available, the oracle restates the published algorithm.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C")
+K = np.array([707.0912, 707.0912, 601.8873, 183.1104])
+
+
+@pytest.fixture(scope="module")
+def host_p3p():
+    path = os.path.join(ROOT, "tests", "cpp", "libp3p_host.so")
+    if not os.path.exists(path):
+        pytest.fail("tests/cpp/libp3p_host.so missing: run __graft_entry__.build()")
+    lib = C.CDLL(path)
+    lib.p3p_host_model.argtypes = [_f64p] * 5
+    lib.p3p_host_solve3.argtypes = [_f64p] * 5
+    return lib
+
+
+def _model(lib, Xw, uv):
+    Rt, rv = np.zeros(12), np.zeros(3)
+    ok = lib.p3p_host_model(np.ascontiguousarray(Xw, np.float64).reshape(12),
+                            np.ascontiguousarray(uv, np.float64).reshape(8), K, Rt, rv)
+    return bool(ok), Rt, rv
+
+
+def _scene(rng, n):
+    rv = rng.normal(size=3) * 0.3
+    R = O.rodrigues_v2m(rv)
+    t = rng.normal(size=3) * np.array([0.5, 0.2, 1.0])
+    Xw = np.stack([rng.uniform(-8, 8, n), rng.uniform(-2, 2, n), rng.uniform(4, 40, n)], 1)
+    Xc = Xw @ R.T + t
+    uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
+    return R, t, Xw, Xc, uv
+
+
+def test_gao_quartic_is_the_resultant():
+    """Gao's closed-form coefficients against the resultant (in y) of the two quadratics they are derived
+    from: (1-a) y^2 + (a r x - p) y + (1 - a x^2) and -b y^2 + b r x y + ((1-b) x^2 - q x + 1)."""
+    P = np.polynomial.polynomial
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        a, b = rng.uniform(0.2, 3.0, 2)
+        p, q, r = rng.uniform(-1.9, 1.9, 3)
+        a1, b1, c1 = np.array([1 - a]), np.array([-p, a * r]), np.array([1, 0, -a])
+        a2, b2, c2 = np.array([-b]), np.array([0, b * r]), np.array([1, -q, 1 - b])
+        t1 = P.polysub(P.polymul(a1, c2), P.polymul(a2, c1))
+        t2 = P.polysub(P.polymul(a1, b2), P.polymul(a2, b1))
+        t3 = P.polysub(P.polymul(b1, c2), P.polymul(b2, c1))
+        res = P.polysub(P.polymul(t1, t1), P.polymul(t2, t3))[::-1]
+        got = O.gao_quartic(a, b, p, q, r)
+        assert np.allclose(got, res, rtol=1e-10, atol=1e-10 * np.abs(res).max())
+
+
+def test_closed_form_quartic_roots():
+    rng = np.random.default_rng(4)
+    checked = 0
+    for _ in range(300):
+        roots = rng.uniform(-3, 3, 4)
+        if np.min(np.abs(roots[:, None] - roots[None, :]) + 10 * np.eye(4)) < 0.05:
+            continue                                     # closed forms lose digits at near-multiple roots
+        coef = np.poly(roots) * rng.uniform(0.5, 2.0)
+        got = np.sort(O.roots4(coef))
+        assert len(got) == 4 and np.abs(got - np.sort(roots)).max() < 1e-7
+        checked += 1
+    assert checked > 200
+    assert len(O.roots4(np.array([1.0, 0, 2.0, 0, 1.0]))) == 0         # (x^2 + 1)^2: no real root
+
+
+def test_library_p3p_against_independent_gao(host_p3p):
+    """Both solvers on the same random quadruples.  The oracle is run as OpenCV 3.x has it (closed-form roots
+    as they come) and with two Newton steps on the roots (the later OpenCV refinement): the library's solver
+    polishes its roots, so it agrees tightly with the second and to the first's own accuracy with the first."""
+    stats = {}
+    for polish in (0, 2):
+        O.p3p_set_polish(polish)
+        rng = np.random.default_rng(7)
+        dif, perr, same_n = [], [], []
+        for _ in range(2000):
+            R, t, Xw, Xc, uv = _scene(rng, 4)
+            if (Xc[:, 2] < 1).any():
+                continue
+            ok_o, Ro, to = O.solve_p3p4(Xw, uv, K)
+            ok_p, Rt, _ = _model(host_p3p, Xw, uv)
+            assert ok_o and ok_p
+            Rs, ts = np.zeros(36), np.zeros(12)
+            n3 = host_p3p.p3p_host_solve3(np.ascontiguousarray(Xw[:3]).reshape(9),
+                                          np.ascontiguousarray(uv[:3]).reshape(6), K, Rs, ts)
+            same_n.append(n3 == len(O.p3p(Xw[:3], uv[:3], K)[0]))
+            dif.append(max(np.abs(Ro - Rt[:9].reshape(3, 3)).max(), np.abs(to - Rt[9:]).max()))
+            perr.append(max(np.abs(Rt[:9].reshape(3, 3) - R).max(), np.abs(Rt[9:] - t).max()))
+        stats[polish] = (np.array(dif), np.array(perr), np.mean(same_n))
+    O.p3p_set_polish(0)
+    d0, perr, same0 = stats[0]
+    d2, _, same2 = stats[2]
+    assert len(d0) > 1900
+    assert np.median(perr) < 1e-11 and np.percentile(perr, 99) < 1e-7      # library vs ground truth
+    assert same0 > 0.995 and same2 > 0.995                                 # same number of poses
+    assert np.median(d2) < 1e-9 and np.percentile(d2, 90) < 1e-7 and np.percentile(d2, 99) < 1e-4
+    assert np.median(d0) < 1e-8 and np.percentile(d0, 90) < 1e-5
+
+
+def _replay(lib, X3, x2, log, n_iters_cap):
+    """The library's hypothesis models for the index quadruples the oracle drew, scored by the oracle's
+    projection: what ktlvo_solve_pnp_ransac counts, minus the GPU."""
+    thr_sq = np.float32(float(np.float32(0.1)) ** 2)
+    out = []
+    for it in range(min(len(log), n_iters_cap)):
+        idx = log[it, :4]
+        ok, Rt, rv = _model(lib, X3[idx].astype(np.float64), x2[idx].astype(np.float64))
+        cnt = O.project_score(X3, x2, Rt, K, thr_sq)[0] if ok else 0
+        out.append((ok, cnt, Rt, rv))
+    return out
+
+
+@pytest.mark.parametrize("seed,noise,n", [(41, 0.04, 400), (5, 0.03, 1500), (17, 0.02, 600)])
+def test_ransac_hypothesis_counts_against_independent_gao(host_p3p, seed, noise, n):
+    """Per-hypothesis inlier counts of the library's solver equal those of the oracle's RANSAC (Gao P3P) on
+    planted-pose problems, up to hypotheses whose pose the closed-form solver resolves poorly; the best
+    hypothesis, its count and its mask are the same."""
+    rng = np.random.default_rng(seed)
+    R = O.rodrigues_v2m(np.array([0.004, -0.012, 0.002]))
+    t = np.array([0.02, -0.01, -0.8])
+    Xw = np.stack([rng.uniform(-8, 8, n), rng.uniform(-2, 2, n), rng.uniform(4, 38, n)], 1).astype(np.float32)
+    Xc = Xw.astype(np.float64) @ R.T + t
+    uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
+    uv += rng.normal(size=uv.shape) * noise
+    uv[: n // 5] += rng.normal(size=(n // 5, 2)) * 6
+    uv = uv.astype(np.float32)
+    r = O.solve_pnp_ransac(Xw, uv, K, max_iters=300)
+    assert r["ok"]
+    log = r["log"]
+    rep = _replay(host_p3p, Xw, uv, log, 300)
+    same = sum(1 for it, (ok, cnt, _, _) in enumerate(rep) if ok == bool(log[it, 4]) and cnt == log[it, 5])
+    assert same >= len(rep) - max(1, len(rep) // 20), (same, len(rep))
+    best = int(np.argmax([c for _, c, _, _ in rep]))        # strict '>' acceptance keeps the first maximum
+    assert rep[best][1] == r["n_inliers"]
+    thr_sq = np.float32(float(np.float32(0.1)) ** 2)
+    assert np.array_equal(O.project_score(Xw, uv, rep[best][2], K, thr_sq)[1], r["mask"])
+    assert np.abs(rep[best][3] - r["rvec"]).max() < 1e-8 and np.abs(rep[best][2][9:] - r["tvec"]).max() < 1e-8
