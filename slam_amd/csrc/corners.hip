@@ -1,15 +1,26 @@
 // Corner detection for gfx950: cv::GFTTDetector::detect -> cv::goodFeaturesToTrack as the reference
 // runs it per sub-region (featureTracking.cpp:102-103, 408-430), and on whole frames.
 //
-//   corner_response_tile  cornerEigenValsVecs (Sobel 3x3, 3x3 box) + calcHarris / calcMinEigenVal;
-//                         a 34x34 covariance tile is staged in LDS, the response map and the
-//                         ROI maximum (minMaxLoc) go to global memory
-//   corner_nms_compact    threshold (THRESH_TOZERO at quality*max), 3x3 dilate-equality test,
-//                         compaction of (value, raster index) keys
-//   corner_select         per ROI: bitonic sort of the keys in LDS (std::sort(greaterThanPtr)),
-//                         then the greedy minimum-distance pass over a cell grid in LDS
-// ROIs larger than 4096 pixels keep the first two kernels and do the (inherently sequential)
-// sort + greedy pass on the host.
+//   corner_candidates     cornerEigenValsVecs (Sobel 3x3, 3x3 box) + calcHarris / calcMinEigenVal, the
+//                         ROI maximum (minMaxLoc) and the 3x3 local-maximum test in ONE pass over the
+//                         image: image, covariance and response tiles live in LDS, only candidate keys
+//                         (value, raster index) and the ROI maximum go to global memory.  The response
+//                         map is never written (ktlvo_corner_response, a test hook, asks for it).
+//   corner_select         per ROI of at most 4096 pixels: bitonic sort of the keys in LDS
+//                         (std::sort(greaterThanPtr)), threshold at quality * max, then the greedy
+//                         minimum-distance pass over a cell grid in LDS
+//   cand_filter, bitonic_*, corner_select_large
+//                         the same for larger ROIs (whole frames): keys above the threshold are
+//                         compacted, sorted in global memory, and one workgroup runs the greedy pass
+//                         over chunks of 512 candidates against a cell grid in global memory
+//
+// goodFeaturesToTrack thresholds the response map at quality * max (THRESH_TOZERO), dilates it 3x3 and
+// keeps pixels that equal the dilated value.  For a pixel above a non-negative threshold that is the
+// same as "not smaller than any of its eight raw neighbours": a neighbour at or below the threshold
+// counts as zero, which is smaller anyway.  So the local-maximum test does not need the threshold, and
+// the one pass emits every positive local maximum; the threshold, known once the whole ROI has been
+// seen, is applied to the sorted keys.  An ROI whose maximum is not positive has no corners (for
+// quality <= 1 nothing exceeds quality * max then), and none are emitted.
 #include "ctx.hpp"
 #include "internal.hpp"
 
@@ -20,13 +31,10 @@
 
 namespace ktlvo {
 
-struct RoiDev {
-    int x, y, w, h;
-    int off; // offset of this ROI's pixels in the response / candidate arrays
-};
-
-constexpr int CT = 32;       // response tile
-constexpr int CC = CT + 2;   // covariance tile
+constexpr int CT = 32;     // response tile owned by a workgroup
+constexpr int CI = CT + 6; // image tile (3-pixel frame)
+constexpr int CC = CT + 4; // covariance tile (2-pixel frame)
+constexpr int CR = CT + 2; // response tile with its 1-pixel frame for the local-maximum test
 constexpr int SEL_MAX = 4096;  // largest ROI area / candidate count handled by corner_select
 constexpr int CELL_MAX = 1024; // largest min-distance cell grid handled by corner_select
 
@@ -36,7 +44,8 @@ __device__ __forceinline__ int reflect101d(int p, int n) {
     return p;
 }
 
-// monotone float -> uint map so the ROI maximum can be taken with atomicMax
+// monotone float -> uint map: the ROI maximum is taken with atomicMax on it, and candidate keys carry
+// it in their upper half so that one unsigned compare orders them by value for either sign
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -48,26 +57,53 @@ __device__ __host__ __forceinline__ float ord2f(unsigned u) {
     return f;
 }
 
-__global__ __launch_bounds__(256) void corner_response_tile(const SlotDesc *slots, int slot, const RoiDev *rois,
-                                                            float s1, float s2, int harris, double k, float *resp,
-                                                            unsigned *roi_max) {
+// Writes the ROI table into device memory and clears the per-ROI maxima and counters: one launch
+// instead of a copy from pageable memory and two memsets (and no allocation on any path).
+__global__ void corner_setup(RoiTable t, int n_roi, RoiDev *rois, unsigned *roi_max, int *cand_cnt, int *overflow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_roi) {
+        RoiDev r;
+        r.x = t.r[i].x; r.y = t.r[i].y; r.w = t.r[i].w; r.h = t.r[i].h; r.off = t.r[i].off;
+        rois[i] = r;
+        roi_max[i] = 0u;
+        cand_cnt[i] = 0;
+    }
+    if (i == 0) *overflow = 0;
+}
+
+__global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, int slot, const RoiDev *rois, float s1,
+                                                         float s2, int harris, double k, float *resp_out,
+                                                         unsigned *roi_max, unsigned long long *cand, int *cand_cnt) {
     const RoiDev R = rois[blockIdx.z];
     const int tx0 = blockIdx.x * CT, ty0 = blockIdx.y * CT;
     if (tx0 >= R.w || ty0 >= R.h) return;
     const LevelDesc L = slots[slot].lv[0];
+    __shared__ uint8_t img[CI][CI + 2];
     __shared__ float cxx[CC][CC + 1], cxy[CC][CC + 1], cyy[CC][CC + 1];
+    __shared__ float rsp[CR][CR + 1];
+    __shared__ int wave_cnt[4][4];
+    __shared__ int block_base;
     const int tid = threadIdx.x;
 
+    // image tile: ROI-relative (tx0 - 3 + ix, ty0 - 3 + iy).  Sobel reads the PARENT image beyond the ROI
+    // (cv::Sobel on a view is not BORDER_ISOLATED; the level's reflect-101 frame is materialised), so the
+    // tile is fetched unreflected; only the pixels a covariance sample can touch are needed.
+    for (int i = tid; i < CI * CI; i += 256) {
+        const int iy = i / CI, ix = i - iy * CI;
+        const int rx = tx0 - 3 + ix, ry = ty0 - 3 + iy;
+        uint8_t v = 0;
+        if (rx >= -1 && rx <= R.w && ry >= -1 && ry <= R.h) v = L.origin[(ptrdiff_t)(R.y + ry) * L.pitch + (R.x + rx)];
+        img[iy][ix] = v;
+    }
+    __syncthreads();
+    // covariance tile: ROI-relative (tx0 - 2 + cx, ty0 - 2 + cy); the box filter runs on the ROI-sized
+    // covariance image and reflects at the ROI's own edges
     for (int i = tid; i < CC * CC; i += 256) {
         const int cy = i / CC, cx = i - cy * CC;
-        // the box filter reflects at the ROI's own edges ...
-        const int x = reflect101d(tx0 - 1 + cx, R.w), y = reflect101d(ty0 - 1 + cy, R.h);
-        // ... while Sobel reads the parent image (its reflect-101 frame is materialised)
-        const uint8_t *p = L.origin + (ptrdiff_t)(R.y + y) * L.pitch + (R.x + x);
-        const int P = L.pitch;
-        const float a00 = p[-P - 1], a01 = p[-P], a02 = p[-P + 1];
-        const float a10 = p[-1], a12 = p[1];
-        const float a20 = p[P - 1], a21 = p[P], a22 = p[P + 1];
+        const int x = reflect101d(tx0 - 2 + cx, R.w) - (tx0 - 3), y = reflect101d(ty0 - 2 + cy, R.h) - (ty0 - 3);
+        const float a00 = img[y - 1][x - 1], a01 = img[y - 1][x], a02 = img[y - 1][x + 1];
+        const float a10 = img[y][x - 1], a12 = img[y][x + 1];
+        const float a20 = img[y + 1][x - 1], a21 = img[y + 1][x], a22 = img[y + 1][x + 1];
         const float r0 = a02 - a00, r1 = a12 - a10, r2 = a22 - a20;
         const float dx = (r0 + r2) * s1 + r1 * s2;
         float q0 = s1 * a00; q0 += s2 * a01; q0 += s1 * a02;
@@ -76,99 +112,86 @@ __global__ __launch_bounds__(256) void corner_response_tile(const SlotDesc *slot
         cxx[cy][cx] = dx * dx; cxy[cy][cx] = dx * dy; cyy[cy][cx] = dy * dy;
     }
     __syncthreads();
-
+    // response tile: ROI-relative (tx0 - 1 + px, ty0 - 1 + py), inside the ROI only
     float vmax = -INFINITY;
-    for (int i = tid; i < CT * CT; i += 256) {
-        const int py = i / CT, px = i - py * CT;
-        const int x = tx0 + px, y = ty0 + py;
-        if (x >= R.w || y >= R.h) continue;
-        double a = 0, b = 0, c = 0;
+    for (int i = tid; i < CR * CR; i += 256) {
+        const int py = i / CR, px = i - py * CR;
+        const int x = tx0 - 1 + px, y = ty0 - 1 + py;
+        float r = -INFINITY;
+        if (x >= 0 && y >= 0 && x < R.w && y < R.h) {
+            double a = 0, b = 0, c = 0; // cv::boxFilter sums float input in double
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            double ra = 0, rb = 0, rc = 0;
+            for (int j = 0; j < 3; j++) {
+                double ra = 0, rb = 0, rc = 0;
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                ra += (double)cxx[py + j][px + q];
-                rb += (double)cxy[py + j][px + q];
-                rc += (double)cyy[py + j][px + q];
+                for (int q = 0; q < 3; q++) {
+                    ra += (double)cxx[py + j][px + q];
+                    rb += (double)cxy[py + j][px + q];
+                    rc += (double)cyy[py + j][px + q];
+                }
+                a += ra; b += rb; c += rc;
             }
-            a += ra; b += rb; c += rc;
+            const float fa = (float)a, fb = (float)b, fc = (float)c;
+            if (harris) {
+                const float t = fa * fc - fb * fb;
+                r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
+            } else {
+                const float ha = fa * 0.5f, hc = fc * 0.5f;
+                r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
+            }
+            if (px >= 1 && py >= 1 && px <= CT && py <= CT) { // this workgroup's own pixels
+                vmax = fmaxf(vmax, r);
+                if (resp_out) resp_out[R.off + y * R.w + x] = r;
+            }
         }
-        const float fa = (float)a, fb = (float)b, fc = (float)c;
-        float r;
-        if (harris) {
-            const float t = fa * fc - fb * fb;
-            r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
-        } else {
-            const float ha = fa * 0.5f, hc = fc * 0.5f;
-            r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
-        }
-        resp[R.off + y * R.w + x] = r;
-        vmax = fmaxf(vmax, r);
+        rsp[py][px] = r;
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(&roi_max[blockIdx.z], f2ord(vmax));
-}
+    if (!cand) return;
+    __syncthreads();
 
-// A workgroup covers 64 x 16 pixels of one ROI.  Candidates are counted per wave (ballot), the four
-// waves' counts meet in LDS, and the workgroup takes its places in the ROI's list with ONE global
-// atomic: returning atomics on a single address serialise in L2 (about 12 ns each), which made a
-// textured whole frame (thousands of local maxima, one counter) cost 60 us when every wave bumped it.
-// The order of candidates in the list does not matter: the keys are sorted later and are unique.
-constexpr int NMS_ROWS = 16;
-__global__ __launch_bounds__(256) void corner_nms_compact(const RoiDev *rois, const float *resp,
-                                                          const unsigned *roi_max, double quality,
-                                                          unsigned long long *cand, int *cand_cnt) {
-    const RoiDev R = rois[blockIdx.z];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    const double maxVal = (double)ord2f(roi_max[blockIdx.z]);
-    const float thr = (float)(maxVal * quality);
-    __shared__ int wave_cnt[4][NMS_ROWS / 4];
-    __shared__ int block_base;
-    unsigned long long votes[NMS_ROWS / 4];
-    float vals[NMS_ROWS / 4];
+    // positive local maxima of the interior (goodFeaturesToTrack scans 1 <= x < w - 1, 1 <= y < h - 1).
+    // Candidates are counted per wave (ballot), the counts meet in LDS and the workgroup takes its places
+    // in the ROI's list with ONE global atomic: returning atomics on a single address serialise in L2.
+    // The order of candidates in the list does not matter: the keys are sorted later and are unique.
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long votes[4];
+    float vals[4];
 #pragma unroll
-    for (int k = 0; k < NMS_ROWS / 4; k++) { // wave w takes rows w, w + 4, ...
-        const int y = blockIdx.y * NMS_ROWS + wave + 4 * k;
-        bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1;
-        float v = 0.f;
+    for (int q = 0; q < 4; q++) {
+        const int i = tid + 256 * q, oy = i / CT, ox = i - oy * CT;
+        const int x = tx0 + ox, y = ty0 + oy;
+        const float v = rsp[oy + 1][ox + 1];
+        bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1 && v > 0.f;
         if (keep) {
-            const float *e = resp + R.off + y * R.w + x;
-            v = e[0] > thr ? e[0] : 0.f;
-            keep = v != 0.f;
-            if (keep) {
-                float m = v;
+            float m = v;
 #pragma unroll
-                for (int j = -1; j <= 1; j++)
+            for (int j = 0; j < 3; j++)
 #pragma unroll
-                    for (int i = -1; i <= 1; i++) {
-                        const float t = e[j * R.w + i];
-                        m = fmaxf(m, t > thr ? t : 0.f);
-                    }
-                keep = v == m;
-            }
+                for (int p = 0; p < 3; p++) m = fmaxf(m, rsp[oy + j][ox + p]);
+            keep = v == m;
         }
-        vals[k] = v;
-        votes[k] = __ballot(keep);
-        if (lane == 0) wave_cnt[wave][k] = __popcll(votes[k]);
+        vals[q] = v;
+        votes[q] = __ballot(keep);
+        if (lane == 0) wave_cnt[wave][q] = __popcll(votes[q]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         int total = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++)
 #pragma unroll
-            for (int k = 0; k < NMS_ROWS / 4; k++) { const int c = wave_cnt[w][k]; wave_cnt[w][k] = total; total += c; }
+            for (int q = 0; q < 4; q++) { const int c = wave_cnt[w][q]; wave_cnt[w][q] = total; total += c; }
         block_base = total ? atomicAdd(&cand_cnt[blockIdx.z], total) : 0;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NMS_ROWS / 4; k++) {
-        if (!((votes[k] >> lane) & 1ull)) continue;
-        const int y = blockIdx.y * NMS_ROWS + wave + 4 * k;
-        const int place = block_base + wave_cnt[wave][k] + __popcll(votes[k] & ((1ull << lane) - 1ull));
-        cand[R.off + place] = ((unsigned long long)__float_as_uint(vals[k]) << 32) | (unsigned)(y * R.w + x);
+    for (int q = 0; q < 4; q++) {
+        if (!((votes[q] >> lane) & 1ull)) continue;
+        const int i = tid + 256 * q, oy = i / CT, ox = i - oy * CT;
+        const int place = block_base + wave_cnt[wave][q] + __popcll(votes[q] & ((1ull << lane) - 1ull));
+        cand[R.off + place] = ((unsigned long long)f2ord(vals[q]) << 32) | (unsigned)((ty0 + oy) * R.w + (tx0 + ox));
     }
 }
 
@@ -176,6 +199,8 @@ struct SelArgs {
     const RoiDev *rois;
     const unsigned long long *cand;
     const int *cand_cnt;
+    const unsigned *roi_max;
+    double quality;
     int max_corners, cap;
     double min_dist;
     float *xy, *resp;
@@ -183,21 +208,29 @@ struct SelArgs {
     int *overflow;
 };
 
+// goodFeaturesToTrack's threshold for an ROI whose maximum response is maxVal: eig > maxVal * quality
+// (cv::threshold(eig, eig, maxVal * qualityLevel, 0, THRESH_TOZERO) on a float image)
+__device__ __forceinline__ float roi_threshold(unsigned max_ord, double quality) {
+    return (float)((double)ord2f(max_ord) * quality);
+}
+
 // Keys sort descending by value, ties by higher raster index first.
 __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
     const int roi = blockIdx.x;
     const RoiDev R = a.rois[roi];
-    const int n = a.cand_cnt[roi];
+    int n = a.cand_cnt[roi];
     const int tid = threadIdx.x;
     __shared__ unsigned long long keys[SEL_MAX];
     __shared__ unsigned short cell_cnt[CELL_MAX];
     __shared__ unsigned cell_pts[CELL_MAX][4]; // x | y << 16
+    __shared__ int n_above;
     if (n > SEL_MAX || R.w * R.h > SEL_MAX) {
-        if (tid == 0) { *a.overflow = 1; a.counts[roi] = 0; }
+        if (tid == 0) { *a.overflow = 1; a.counts[roi] = -1; }
         return;
     }
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
+    if (tid == 0) n_above = 0;
     for (int i = tid; i < np2; i += 256) keys[i] = i < n ? a.cand[R.off + i] : 0ull;
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1)
@@ -212,6 +245,15 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
             }
             __syncthreads();
         }
+    { // the keys above the threshold are a prefix of the sorted list
+        const float thr = roi_threshold(a.roi_max[roi], a.quality);
+        int c = 0;
+        for (int i = tid; i < n; i += 256) c += ord2f((unsigned)(keys[i] >> 32)) > thr;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if ((tid & 63) == 0 && c) atomicAdd(&n_above, c);
+        __syncthreads();
+        n = n_above;
+    }
 
     float *oxy = a.xy + (size_t)roi * a.cap * 2;
     float *oresp = a.resp + (size_t)roi * a.cap;
@@ -221,7 +263,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
         for (int i = tid; i < m; i += 256) {
             const unsigned idx = (unsigned)keys[i];
             oxy[2 * i] = (float)(idx % R.w); oxy[2 * i + 1] = (float)(idx / R.w);
-            oresp[i] = __uint_as_float((unsigned)(keys[i] >> 32));
+            oresp[i] = ord2f((unsigned)(keys[i] >> 32));
         }
         if (tid == 0) a.counts[roi] = m;
         return;
@@ -229,7 +271,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
     const int cell = __double2int_rn(a.min_dist);
     const int gw = (R.w + cell - 1) / cell, gh = (R.h + cell - 1) / cell;
     if (gw * gh > CELL_MAX) { // the host checks this before launching
-        if (tid == 0) { *a.overflow = 1; a.counts[roi] = 0; }
+        if (tid == 0) { *a.overflow = 1; a.counts[roi] = -1; }
         return;
     }
     for (int i = tid; i < gw * gh; i += 256) cell_cnt[i] = 0;
@@ -267,7 +309,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
             vpts[ci][cnt] = (unsigned)x | ((unsigned)y << 16);
             vcnt[ci] = (unsigned short)(cnt + 1);
             oxy[2 * ncorners] = (float)x; oxy[2 * ncorners + 1] = (float)y;
-            oresp[ncorners] = __uint_as_float((unsigned)(keys[i] >> 32));
+            oresp[ncorners] = ord2f((unsigned)(keys[i] >> 32));
         }
         __builtin_amdgcn_wave_barrier();
         ++ncorners;
@@ -276,91 +318,240 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
     if (tid == 0) a.counts[roi] = ncorners;
 }
 
-// Host form of the sort + greedy pass for large ROIs (same rule as corner_select).
-static int host_select(const RoiDev &R, std::vector<unsigned long long> &keys, const ktlvo_gftt_params &p, int cap,
-                       float *xy, float *resp) {
-    std::sort(keys.begin(), keys.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
-    const int limit = p.max_corners > 0 ? std::min(p.max_corners, cap) : cap;
-    int ncorners = 0;
-    auto emit = [&](unsigned long long key, int x, int y) {
-        xy[2 * ncorners] = (float)x; xy[2 * ncorners + 1] = (float)y;
-        unsigned b = (unsigned)(key >> 32);
-        float f;
-        __builtin_memcpy(&f, &b, 4);
-        resp[ncorners] = f;
-        ++ncorners;
-    };
-    if (p.min_dist < 1) {
-        for (unsigned long long key : keys) {
-            if (ncorners == limit) break;
-            const unsigned idx = (unsigned)key;
-            emit(key, idx % R.w, idx / R.w);
+// ---- large ROIs (whole frames) ---------------------------------------------------------------------------
+// Keys of one ROI whose value exceeds the ROI's threshold, compacted (in any order) into out[]; the
+// remainder of out[] up to out_cap is cleared so that a power-of-two sort can run over it.
+__global__ __launch_bounds__(256) void cand_filter(const unsigned long long *cand, const int *cand_cnt,
+                                                   const unsigned *roi_max, double quality, unsigned long long *out,
+                                                   int *out_cnt) {
+    const int n = *cand_cnt;
+    const float thr = roi_threshold(*roi_max, quality);
+    __shared__ int wave_off[4];
+    __shared__ int block_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) { // uniform trip count per workgroup
+        const int i = base + threadIdx.x;
+        unsigned long long key = 0;
+        bool keep = false;
+        if (i < n) {
+            key = cand[i];
+            keep = ord2f((unsigned)(key >> 32)) > thr;
         }
-        return ncorners;
+        const unsigned long long vote = __ballot(keep);
+        if (lane == 0) wave_off[wave] = __popcll(vote);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0;
+            for (int w = 0; w < 4; w++) { const int c = wave_off[w]; wave_off[w] = total; total += c; }
+            block_base = total ? atomicAdd(out_cnt, total) : 0;
+        }
+        __syncthreads();
+        if (keep) out[block_base + wave_off[wave] + __popcll(vote & ((1ull << lane) - 1ull))] = key;
+        __syncthreads();
     }
-    const int cell = (int)lrint(p.min_dist);
-    const int gw = (R.w + cell - 1) / cell, gh = (R.h + cell - 1) / cell;
-    std::vector<std::vector<unsigned>> grid((size_t)gw * gh);
-    const double md2 = p.min_dist * p.min_dist;
-    for (unsigned long long key : keys) {
-        const unsigned idx = (unsigned)key;
-        const int y = idx / R.w, x = idx % R.w;
-        const int xc = x / cell, yc = y / cell;
-        bool good = true;
-        for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1) && good; yy++)
-            for (int xx = std::max(0, xc - 1); xx <= std::min(gw - 1, xc + 1) && good; xx++)
-                for (unsigned q : grid[(size_t)yy * gw + xx]) {
-                    const float dx = (float)x - (float)(q & 0xffff), dy = (float)y - (float)(q >> 16);
-                    if ((double)(dx * dx + dy * dy) < md2) { good = false; break; }
-                }
-        if (!good) continue;
-        grid[(size_t)yc * gw + xc].push_back((unsigned)x | ((unsigned)y << 16));
-        emit(key, x, y);
-        if (ncorners == limit) break;
-    }
-    return ncorners;
 }
 
-struct CornerWork {
-    RoiDev *d_rois;
-    float *d_resp;
-    unsigned *d_max;
-    int *d_cnt;
-    int *d_overflow;
-    unsigned long long *d_cand;
-    float *d_xy, *d_oresp;
-    int *d_counts;
-    // the results (xy, responses, counts, overflow flag) are adjacent: out_bytes from d_xy on
-    size_t off_oresp, off_counts, off_overflow, out_bytes;
+// Bitonic sort, descending, of np2 (a power of two) keys in global memory.  A workgroup owns BL
+// consecutive keys in LDS for all compare distances below BL; larger distances run as global steps.
+constexpr int BL = 4096;
+__device__ __forceinline__ void bitonic_lds_steps(unsigned long long *s, int n_local, size_t gbase, size_t k, int j_from) {
+    for (int j = j_from; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < n_local; i += blockDim.x) {
+            const int p = i ^ j;
+            if (p > i) {
+                const unsigned long long x = s[i], y = s[p];
+                const bool desc = ((gbase + i) & k) == 0;
+                if (desc ? x < y : x > y) { s[i] = y; s[p] = x; }
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(512) void bitonic_local_sort(unsigned long long *keys, int np2) {
+    __shared__ unsigned long long s[BL];
+    const int n_local = np2 < BL ? np2 : BL;
+    const size_t gbase = (size_t)blockIdx.x * BL;
+    for (int i = threadIdx.x; i < n_local; i += blockDim.x) s[i] = keys[gbase + i];
+    __syncthreads();
+    for (int k = 2; k <= n_local; k <<= 1) bitonic_lds_steps(s, n_local, gbase, (size_t)k, k >> 1);
+    for (int i = threadIdx.x; i < n_local; i += blockDim.x) keys[gbase + i] = s[i];
+}
+__global__ __launch_bounds__(512) void bitonic_local_merge(unsigned long long *keys, unsigned k) {
+    __shared__ unsigned long long s[BL];
+    const size_t gbase = (size_t)blockIdx.x * BL;
+    for (int i = threadIdx.x; i < BL; i += blockDim.x) s[i] = keys[gbase + i];
+    __syncthreads();
+    bitonic_lds_steps(s, BL, gbase, (size_t)k, BL >> 1);
+    for (int i = threadIdx.x; i < BL; i += blockDim.x) keys[gbase + i] = s[i];
+}
+__global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *keys, unsigned j, unsigned k) {
+    // thread t owns the pair (i, i | j) with i = t with a zero bit inserted at position log2(j)
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((t & ~((size_t)j - 1)) << 1) | (t & ((size_t)j - 1));
+    const size_t p = i | j;
+    const unsigned long long x = keys[i], y = keys[p];
+    const bool desc = (i & k) == 0;
+    if (desc ? x < y : x > y) { keys[i] = y; keys[p] = x; }
+}
+
+struct SelLargeArgs {
+    const unsigned long long *keys; // sorted descending
+    const int *n_ptr;               // number of keys above the threshold
+    int w, h;
+    double min_dist;
+    int cell, gw, gh;
+    int *cell_cnt;      // gw * gh, cleared
+    unsigned *cell_pts; // gw * gh * 4: x | y << 16
+    int limit;
+    float *xy, *resp;
+    int *count;
+    int *overflow;
 };
+constexpr int CH = 512; // candidates per chunk of the greedy pass
 
-static int carve(ktlvo_ctx *ctx, int n_roi, size_t total_px, int cap, CornerWork &w) {
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t o_rois = 0;
-    size_t o_resp = o_rois + up(sizeof(RoiDev) * n_roi);
-    size_t o_max = o_resp + up(total_px * 4);
-    size_t o_cnt = o_max + up(4 * (size_t)n_roi);
-    size_t o_cand = o_cnt + up(4 * (size_t)n_roi);
-    size_t o_xy = o_cand + up(total_px * 8);
-    size_t o_or = o_xy + up((size_t)n_roi * cap * 8);
-    size_t o_counts = o_or + up((size_t)n_roi * cap * 4);
-    size_t o_ovf = o_counts + up(4 * (size_t)n_roi);
-    size_t total = o_ovf + 256;
-    int rc = ensure_misc(ctx, total);
-    if (rc != KTLVO_OK) return rc;
-    char *b = (char *)ctx->d_misc;
-    w.d_rois = (RoiDev *)(b + o_rois); w.d_resp = (float *)(b + o_resp); w.d_max = (unsigned *)(b + o_max);
-    w.d_cnt = (int *)(b + o_cnt); w.d_overflow = (int *)(b + o_ovf); w.d_cand = (unsigned long long *)(b + o_cand);
-    w.d_xy = (float *)(b + o_xy); w.d_oresp = (float *)(b + o_or); w.d_counts = (int *)(b + o_counts);
-    w.off_oresp = o_or - o_xy; w.off_counts = o_counts - o_xy; w.off_overflow = o_ovf - o_xy;
-    w.out_bytes = o_ovf + 4 - o_xy;
-    return KTLVO_OK;
+// goodFeaturesToTrack's greedy pass: walk the candidates in sorted order and accept one unless an accepted
+// corner lies closer than min_dist.  A candidate's fate depends only on the accepted corners ranked before
+// it, so a chunk of CH consecutive candidates is handled in parallel: (1) every candidate is tested
+// against the corners accepted from earlier chunks (cell grid in global memory, owned by this single
+// workgroup); (2) the survivors are compacted in rank order and each finds the survivors ranked before it
+// that are too close (a bit mask per survivor); (3) rounds in which a survivor with an accepted
+// predecessor in its mask is rejected, and one whose predecessors are all rejected is accepted, until all
+// are decided -- the lowest undecided survivor always decides, and chains are short because a chunk's
+// candidates are scattered over the frame; (4) the accepted ones take their output places in rank order
+// and enter the grid.
+__global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
+    __shared__ unsigned long long s_key[CH];
+    __shared__ int s_x[CH], s_y[CH];
+    __shared__ unsigned conf[CH][CH / 32];
+    __shared__ unsigned accm[CH / 32], rejm[CH / 32];
+    __shared__ int wave_off[CH / 64 + 1];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = *a.n_ptr;
+    const float md = (float)a.min_dist;
+    const double md2 = a.min_dist * a.min_dist;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += CH) {
+        const int total0 = s_total;
+        if (total0 >= a.limit) break;
+        // (1) against the grid
+        const int i = base + tid;
+        unsigned long long key = 0;
+        int x = 0, y = 0;
+        bool surv = false;
+        if (i < n) {
+            key = a.keys[i];
+            const unsigned idx = (unsigned)key;
+            y = idx / a.w; x = idx - y * a.w;
+            const int xc = x / a.cell, yc = y / a.cell;
+            surv = true;
+            for (int cy = max(yc - 1, 0); cy <= min(yc + 1, a.gh - 1) && surv; cy++)
+                for (int cx = max(xc - 1, 0); cx <= min(xc + 1, a.gw - 1) && surv; cx++) {
+                    const int ci = cy * a.gw + cx;
+                    const int cnt = min(__hip_atomic_load(&a.cell_cnt[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 4);
+                    for (int s = 0; s < cnt; s++) {
+                        const unsigned p = __hip_atomic_load(&a.cell_pts[4 * ci + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const float dx = (float)x - (float)(p & 0xffff), dy = (float)y - (float)(p >> 16);
+                        if ((double)(dx * dx + dy * dy) < md2) { surv = false; break; }
+                    }
+                }
+        }
+        // (2) survivors in rank order
+        const unsigned long long vote = __ballot(surv);
+        if (lane == 0) wave_off[wave] = __popcll(vote);
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < CH / 64; w++) { const int c = wave_off[w]; wave_off[w] = t; t += c; }
+            wave_off[CH / 64] = t;
+        }
+        __syncthreads();
+        const int S = wave_off[CH / 64];
+        if (surv) {
+            const int p = wave_off[wave] + __popcll(vote & ((1ull << lane) - 1ull));
+            s_key[p] = key; s_x[p] = x; s_y[p] = y;
+        }
+        __syncthreads();
+        // survivor `tid` against the survivors ranked before it
+        int state = 3; // 0 undecided, 1 accepted, 2 rejected, 3 not a survivor
+        if (tid < S) {
+            const int mx = s_x[tid], my = s_y[tid];
+            unsigned word = 0, any = 0;
+            for (int q = 0; q < tid; q++) {
+                const float dx = (float)(mx - s_x[q]), dy = (float)(my - s_y[q]);
+                if (fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2) word |= 1u << (q & 31);
+                if ((q & 31) == 31) { conf[tid][q >> 5] = word; any |= word; word = 0; }
+            }
+            any |= word;
+            for (int wq = tid >> 5; wq < CH / 32; wq++) { conf[tid][wq] = word; word = 0; }
+            state = any ? 0 : 1;
+        }
+        // (3) rounds
+        for (;;) {
+            const unsigned long long va = __ballot(state == 1), vr = __ballot(state == 2);
+            if (lane == 0) {
+                accm[2 * wave] = (unsigned)va; accm[2 * wave + 1] = (unsigned)(va >> 32);
+                rejm[2 * wave] = (unsigned)vr; rejm[2 * wave + 1] = (unsigned)(vr >> 32);
+            }
+            __syncthreads();
+            if (state == 0) {
+                bool hit = false, pending = false;
+                for (int wq = 0; wq <= (tid >> 5); wq++) {
+                    const unsigned c = conf[tid][wq];
+                    hit = hit || (c & accm[wq]);
+                    pending = pending || (c & ~(accm[wq] | rejm[wq]));
+                }
+                if (hit) state = 2;
+                else if (!pending) state = 1;
+            }
+            if (!__syncthreads_or(state == 0)) break;
+        }
+        // (4) accepted survivors, in rank order
+        const unsigned long long va = __ballot(state == 1);
+        if (lane == 0) wave_off[wave] = __popcll(va);
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < CH / 64; w++) { const int c = wave_off[w]; wave_off[w] = t; t += c; }
+            s_total = min(total0 + t, a.limit);
+        }
+        __syncthreads();
+        if (state == 1) {
+            const int pos = total0 + wave_off[wave] + __popcll(va & ((1ull << lane) - 1ull));
+            if (pos < a.limit) {
+                const int mx = s_x[tid], my = s_y[tid];
+                a.xy[2 * pos] = (float)mx; a.xy[2 * pos + 1] = (float)my;
+                a.resp[pos] = ord2f((unsigned)(s_key[tid] >> 32));
+                const int ci = (my / a.cell) * a.gw + (mx / a.cell);
+                const int slot = atomicAdd(&a.cell_cnt[ci], 1);
+                if (slot < 4) __hip_atomic_store(&a.cell_pts[4 * ci + slot], (unsigned)mx | ((unsigned)my << 16), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                else *a.overflow = 2; // cannot happen for cell = round(min_dist); reported instead of dropped
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    if (tid == 0) *a.count = s_total;
 }
 
-static int check_rois(const ktlvo_ctx *ctx, const ktlvo_roi *rois, int n_roi, std::vector<RoiDev> &out, size_t &total,
-                      int &maxw, int &maxh) {
+// first `limit` keys of a sorted list, no distance test (min_dist < 1)
+__global__ void corner_take_first(const unsigned long long *keys, const int *n_ptr, int w, int limit, float *xy,
+                                  float *resp, int *count) {
+    const int n = min(*n_ptr, limit);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const unsigned idx = (unsigned)keys[i];
+        xy[2 * i] = (float)(idx % w); xy[2 * i + 1] = (float)(idx / w);
+        resp[i] = ord2f((unsigned)(keys[i] >> 32));
+    }
+    if (i == 0) *count = n;
+}
+
+static int check_rois(const ktlvo_ctx *ctx, const ktlvo_roi *rois, int n_roi, RoiDev *out, size_t &total, int &maxw,
+                      int &maxh) {
     total = 0; maxw = 0; maxh = 0;
-    out.resize(n_roi);
     for (int i = 0; i < n_roi; i++) {
         const ktlvo_roi &r = rois[i];
         if (r.w <= 0 || r.h <= 0 || r.x < 0 || r.y < 0 || r.x + r.w > ctx->cfg.width || r.y + r.h > ctx->cfg.height)
@@ -374,16 +565,150 @@ static int check_rois(const ktlvo_ctx *ctx, const ktlvo_roi *rois, int n_roi, st
     return KTLVO_OK;
 }
 
-static int run_response(ktlvo_ctx *ctx, int slot, const std::vector<RoiDev> &rois, int maxw, int maxh, int use_harris,
-                        double k, const CornerWork &w) {
-    const int n_roi = (int)rois.size();
-    KTLVO_HIP(ctx, hipMemcpyAsync(w.d_rois, rois.data(), sizeof(RoiDev) * n_roi, hipMemcpyHostToDevice, ctx->stream));
-    KTLVO_HIP(ctx, hipMemsetAsync(w.d_max, 0, 4 * (size_t)n_roi, ctx->stream));
+static bool rois_fit_lds(const RoiDev *rois, int n_roi, double min_dist) {
+    for (int i = 0; i < n_roi; i++) {
+        const RoiDev &r = rois[i];
+        if (r.w * r.h > SEL_MAX) return false;
+        if (min_dist >= 1) {
+            const int cell = (int)lrint(min_dist);
+            if (((r.w + cell - 1) / cell) * ((r.h + cell - 1) / cell) > CELL_MAX) return false;
+        }
+    }
+    return true;
+}
+
+size_t corner_scratch_bytes(int n_roi, size_t total_px) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    return up(sizeof(RoiDev) * (size_t)n_roi) + 2 * up(4 * (size_t)n_roi) + 256 + up(total_px * 8);
+}
+
+void corner_scratch_carve(void *base, int n_roi, size_t total_px, CornerScratch &s) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char *b = (char *)base;
+    s.d_rois = (RoiDev *)b; b += up(sizeof(RoiDev) * (size_t)n_roi);
+    s.d_max = (unsigned *)b; b += up(4 * (size_t)n_roi);
+    s.d_cnt = (int *)b; b += up(4 * (size_t)n_roi);
+    s.d_overflow = (int *)b; b += 256;
+    s.d_cand = (unsigned long long *)b;
+    (void)total_px;
+}
+
+// ROI table + cleared counters into the scratch area.  Up to RoiTable::MAX ROIs travel as kernel
+// arguments; longer lists are copied.
+static bool rois_fit_table(const RoiDev *rois, int n_roi) {
+    bool fits = n_roi <= RoiTable::MAX;
+    for (int i = 0; i < n_roi && fits; i++) fits = rois[i].x <= 65535 && rois[i].y <= 65535;
+    return fits;
+}
+
+static int corner_scratch_setup(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const CornerScratch &s) {
+    if (rois_fit_table(rois, n_roi)) {
+        RoiTable t;
+        for (int i = 0; i < n_roi; i++) {
+            t.r[i].x = (uint16_t)rois[i].x; t.r[i].y = (uint16_t)rois[i].y;
+            t.r[i].w = (uint16_t)rois[i].w; t.r[i].h = (uint16_t)rois[i].h; t.r[i].off = rois[i].off;
+        }
+        hipLaunchKernelGGL(corner_setup, dim3((n_roi + 255) / 256), dim3(256), 0, ctx->stream, t, n_roi, s.d_rois, s.d_max,
+                           s.d_cnt, s.d_overflow);
+        KTLVO_HIP(ctx, hipGetLastError());
+        return KTLVO_OK;
+    }
+    KTLVO_HIP(ctx, hipMemcpyAsync(s.d_rois, rois, sizeof(RoiDev) * n_roi, hipMemcpyHostToDevice, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(s.d_max, 0, 4 * (size_t)n_roi, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(s.d_cnt, 0, 4 * (size_t)n_roi, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(s.d_overflow, 0, 4, ctx->stream));
+    return KTLVO_OK;
+}
+
+static int run_candidates(ktlvo_ctx *ctx, int slot, int n_roi, int maxw, int maxh, int use_harris, double k,
+                          const CornerScratch &s, float *d_resp_out, bool want_candidates) {
     const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0); // cornerEigenValsVecs: 2^(ksize-1) * blockSize * 255
     const float s1 = (float)(1.0 * scale), s2 = (float)(2.0 * scale);
     dim3 grid((maxw + CT - 1) / CT, (maxh + CT - 1) / CT, n_roi);
-    hipLaunchKernelGGL(corner_response_tile, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, w.d_rois, s1, s2,
-                       use_harris, k, w.d_resp, w.d_max);
+    hipLaunchKernelGGL(corner_candidates, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois, s1, s2, use_harris, k,
+                       d_resp_out, s.d_max, want_candidates ? s.d_cand : nullptr, s.d_cnt);
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
+// Detection for ROIs that fit corner_select's LDS (the reference's sub-regions): everything is enqueued on the
+// context's stream, nothing is allocated or synchronised; outputs are device arrays [n_roi][cap].
+static int corner_detect_small_dev(ktlvo_ctx *ctx, int slot, const RoiDev *rois, int n_roi, int maxw, int maxh,
+                                   const ktlvo_gftt_params *p, const CornerScratch &s, float *d_xy, float *d_resp,
+                                   int *d_counts, int cap) {
+    int rc = corner_scratch_setup(ctx, rois, n_roi, s);
+    if (rc != KTLVO_OK) return rc;
+    rc = run_candidates(ctx, slot, n_roi, maxw, maxh, p->use_harris, p->harris_k, s, nullptr, true);
+    if (rc != KTLVO_OK) return rc;
+    SelArgs a;
+    a.rois = s.d_rois; a.cand = s.d_cand; a.cand_cnt = s.d_cnt; a.roi_max = s.d_max; a.quality = p->quality;
+    a.max_corners = p->max_corners; a.cap = cap; a.min_dist = p->min_dist;
+    a.xy = d_xy; a.resp = d_resp; a.counts = d_counts; a.overflow = s.d_overflow;
+    hipLaunchKernelGGL(corner_select, dim3(n_roi), dim3(256), 0, ctx->stream, a);
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
+static int ensure_aux(ktlvo_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->aux_bytes) return KTLVO_OK;
+    if (ctx->d_aux) {
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KTLVO_HIP(ctx, hipFree(ctx->d_aux));
+        ctx->d_aux = nullptr;
+        ctx->aux_bytes = 0;
+    }
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    KTLVO_HIP(ctx, hipMalloc(&ctx->d_aux, bytes));
+    ctx->aux_bytes = bytes;
+    return KTLVO_OK;
+}
+
+// Sort + greedy pass of one large ROI on the device.  n_sup = the ROI's candidate count (already on the host).
+static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, const ktlvo_gftt_params *p,
+                        const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap) {
+    if (n_sup == 0) {
+        KTLVO_HIP(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
+        return KTLVO_OK;
+    }
+    size_t np2 = 1;
+    while (np2 < (size_t)n_sup) np2 <<= 1;
+    const bool dist = p->min_dist >= 1;
+    const int cell = dist ? (int)lrint(p->min_dist) : 1;
+    const int gw = dist ? (R.w + cell - 1) / cell : 0, gh = dist ? (R.h + cell - 1) / cell : 0;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_keys = 0, o_n = o_keys + up(np2 * 8), o_cc = o_n + 256, o_cp = o_cc + up((size_t)gw * gh * 4);
+    const size_t total = o_cp + up((size_t)gw * gh * 16);
+    int rc = ensure_aux(ctx, total);
+    if (rc != KTLVO_OK) return rc;
+    char *b = (char *)ctx->d_aux;
+    unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
+    int *d_n = (int *)(b + o_n);
+    // keys and counter cleared in one go (the sort runs over all np2 keys; zeros sort last), then the grid
+    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc + (dist ? up((size_t)gw * gh * 4) : 0), ctx->stream));
+    const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
+    hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
+                       p->quality, d_keys, d_n);
+    KTLVO_HIP(ctx, hipGetLastError());
+    // How many passed is only known on the device; the sort is sized for the candidate count, which bounds it.
+    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL)), dim3(512), 0, ctx->stream, d_keys, (int)np2);
+    for (size_t k = 2 * (size_t)BL; k <= np2; k <<= 1) {
+        for (size_t j = k >> 1; j >= (size_t)BL; j >>= 1)
+            hipLaunchKernelGGL(bitonic_global_step, dim3((unsigned)(np2 / 512)), dim3(256), 0, ctx->stream, d_keys, (unsigned)j,
+                               (unsigned)k);
+        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL)), dim3(512), 0, ctx->stream, d_keys, (unsigned)k);
+    }
+    KTLVO_HIP(ctx, hipGetLastError());
+    const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
+    if (!dist) {
+        hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256), dim3(256), 0, ctx->stream, d_keys, d_n, R.w, limit, d_xy,
+                           d_resp, d_count);
+    } else {
+        SelLargeArgs a;
+        a.keys = d_keys; a.n_ptr = d_n; a.w = R.w; a.h = R.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh;
+        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (unsigned *)(b + o_cp); a.limit = limit;
+        a.xy = d_xy; a.resp = d_resp; a.count = d_count; a.overflow = s.d_overflow;
+        hipLaunchKernelGGL(corner_select_large, dim3(1), dim3(CH), 0, ctx->stream, a);
+    }
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }
@@ -397,17 +722,23 @@ extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *
     if (!ctx || !roi || !out || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
     KTLVO_BIND(ctx);
     if (ctx->built[slot] < 0) return KTLVO_ERR_STATE;
-    std::vector<RoiDev> rois;
+    RoiDev rois[1];
     size_t total;
     int maxw, maxh;
     int rc = check_rois(ctx, roi, 1, rois, total, maxw, maxh);
     if (rc != KTLVO_OK) return rc;
-    CornerWork w;
-    rc = carve(ctx, 1, total, 1, w);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_resp = up(corner_scratch_bytes(1, 0));
+    rc = ensure_misc(ctx, o_resp + total * 4);
     if (rc != KTLVO_OK) return rc;
-    rc = run_response(ctx, slot, rois, maxw, maxh, use_harris, harris_k, w);
+    CornerScratch s;
+    corner_scratch_carve(ctx->d_misc, 1, 0, s);
+    float *d_resp = (float *)((char *)ctx->d_misc + o_resp);
+    rc = corner_scratch_setup(ctx, rois, 1, s);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemcpyAsync(out, w.d_resp, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    rc = run_candidates(ctx, slot, 1, maxw, maxh, use_harris, harris_k, s, d_resp, false);
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemcpyAsync(out, d_resp, total * 4, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KTLVO_OK;
 }
@@ -422,60 +753,57 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
     if (p->max_corners > cap) return KTLVO_ERR_INVALID;
     if (!(p->quality > 0) || !(p->min_dist >= 0)) return KTLVO_ERR_INVALID; // goodFeaturesToTrack's own assertion
     if (ctx->built[slot] < 0) return KTLVO_ERR_STATE;
-    std::vector<RoiDev> rois;
+    std::vector<RoiDev> rois_v(n_roi);
+    RoiDev *rois = rois_v.data();
     size_t total;
     int maxw, maxh;
     int rc = check_rois(ctx, rois_in, n_roi, rois, total, maxw, maxh);
     if (rc != KTLVO_OK) return rc;
-    CornerWork w;
-    rc = carve(ctx, n_roi, total, cap, w);
-    if (rc != KTLVO_OK) return rc;
-    ProfScope ps(ctx, KTLVO_K_CORNER);
-    rc = run_response(ctx, slot, rois, maxw, maxh, p->use_harris, p->harris_k, w);
-    if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemsetAsync(w.d_cnt, 0, 4 * (size_t)n_roi, ctx->stream));
-    KTLVO_HIP(ctx, hipMemsetAsync(w.d_overflow, 0, 4, ctx->stream));
-    dim3 grid((maxw + 63) / 64, (maxh + NMS_ROWS - 1) / NMS_ROWS, n_roi);
-    hipLaunchKernelGGL(corner_nms_compact, grid, dim3(256), 0, ctx->stream, w.d_rois, w.d_resp, w.d_max, p->quality,
-                       w.d_cand, w.d_cnt);
-    KTLVO_HIP(ctx, hipGetLastError());
 
-    bool small = true;
-    for (const RoiDev &r : rois) {
-        small = small && (r.w * r.h <= SEL_MAX);
-        if (p->min_dist >= 1) {
-            const int cell = (int)lrint(p->min_dist);
-            small = small && (((r.w + cell - 1) / cell) * ((r.h + cell - 1) / cell) <= CELL_MAX);
+    // work area: scratch (ROI table, maxima, counters, candidate keys), then the results, adjacent so
+    // that they come home in one copy: xy, responses, counts, overflow flag
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_xy = up(corner_scratch_bytes(n_roi, total));
+    const size_t o_or = o_xy + up((size_t)n_roi * cap * 8), o_counts = o_or + up((size_t)n_roi * cap * 4);
+    const size_t out_bytes = o_counts + 4 * (size_t)n_roi - o_xy;
+    rc = ensure_misc(ctx, o_counts + up(4 * (size_t)n_roi));
+    if (rc != KTLVO_OK) return rc;
+    rc = ensure_pin(ctx, out_bytes + 4 * (size_t)n_roi + 8);
+    if (rc != KTLVO_OK) return rc;
+    CornerScratch s;
+    corner_scratch_carve(ctx->d_misc, n_roi, total, s);
+    char *base = (char *)ctx->d_misc;
+    float *d_xy = (float *)(base + o_xy), *d_oresp = (float *)(base + o_or);
+    int *d_counts = (int *)(base + o_counts);
+    char *hp = (char *)ctx->h_pin;
+
+    ProfScope ps(ctx, KTLVO_K_CORNER);
+    if (rois_fit_lds(rois, n_roi, p->min_dist)) {
+        rc = corner_detect_small_dev(ctx, slot, rois, n_roi, maxw, maxh, p, s, d_xy, d_oresp, d_counts, cap);
+        if (rc != KTLVO_OK) return rc;
+    } else {
+        // larger ROIs (whole frames): the candidate counts size the sort, so they come home first
+        rc = corner_scratch_setup(ctx, rois, n_roi, s);
+        if (rc != KTLVO_OK) return rc;
+        rc = run_candidates(ctx, slot, n_roi, maxw, maxh, p->use_harris, p->harris_k, s, nullptr, true);
+        if (rc != KTLVO_OK) return rc;
+        int *h_cnt = (int *)(hp + out_bytes);
+        KTLVO_HIP(ctx, hipMemcpyAsync(h_cnt, s.d_cnt, 4 * (size_t)n_roi, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int r = 0; r < n_roi; r++) {
+            rc = select_large(ctx, rois[r], r, h_cnt[r], p, s, d_xy + (size_t)r * cap * 2, d_oresp + (size_t)r * cap,
+                              d_counts + r, cap);
+            if (rc != KTLVO_OK) return rc;
         }
     }
-    if (small) {
-        SelArgs a;
-        a.rois = w.d_rois; a.cand = w.d_cand; a.cand_cnt = w.d_cnt; a.max_corners = p->max_corners; a.cap = cap;
-        a.min_dist = p->min_dist; a.xy = w.d_xy; a.resp = w.d_oresp; a.counts = w.d_counts; a.overflow = w.d_overflow;
-        hipLaunchKernelGGL(corner_select, dim3(n_roi), dim3(256), 0, ctx->stream, a);
-        KTLVO_HIP(ctx, hipGetLastError());
-        // one copy home through pinned memory, then into the caller's three arrays
-        rc = ensure_pin(ctx, w.out_bytes);
-        if (rc != KTLVO_OK) return rc;
-        const char *hp = (const char *)ctx->h_pin;
-        KTLVO_HIP(ctx, hipMemcpyAsync(ctx->h_pin, w.d_xy, w.out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        memcpy(xy, hp, (size_t)n_roi * cap * 8);
-        memcpy(response, hp + w.off_oresp, (size_t)n_roi * cap * 4);
-        memcpy(counts, hp + w.off_counts, 4 * (size_t)n_roi);
-        const int ovf = *(const int *)(hp + w.off_overflow);
-        if (ovf) { ctx->last_error = "corner_select: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
-        return KTLVO_OK;
-    }
-    // large ROIs: candidates come back, the sequential pass runs on the host
-    std::vector<int> cnt(n_roi);
-    KTLVO_HIP(ctx, hipMemcpyAsync(cnt.data(), w.d_cnt, 4 * (size_t)n_roi, hipMemcpyDeviceToHost, ctx->stream));
+    // one copy home through pinned memory, then into the caller's three arrays
+    KTLVO_HIP(ctx, hipMemcpyAsync(hp, d_xy, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    int *h_ovf = (int *)(hp + out_bytes + 4 * (size_t)n_roi);
+    KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int r = 0; r < n_roi; r++) {
-        std::vector<unsigned long long> keys(cnt[r]);
-        if (cnt[r] > 0)
-            KTLVO_HIP(ctx, hipMemcpy(keys.data(), w.d_cand + rois[r].off, 8 * (size_t)cnt[r], hipMemcpyDeviceToHost));
-        counts[r] = host_select(rois[r], keys, *p, cap, xy + (size_t)r * cap * 2, response + (size_t)r * cap);
-    }
+    memcpy(xy, hp, (size_t)n_roi * cap * 8);
+    memcpy(response, hp + (o_or - o_xy), (size_t)n_roi * cap * 4);
+    memcpy(counts, hp + (o_counts - o_xy), 4 * (size_t)n_roi);
+    if (*h_ovf) { ctx->last_error = "corner selection: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
     return KTLVO_OK;
 }

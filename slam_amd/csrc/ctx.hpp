@@ -86,6 +86,8 @@ struct ktlvo_ctx {
     int *d_idx = nullptr;   // max_points + 1 ints
     void *d_misc = nullptr; // corner / ransac work area
     size_t misc_bytes = 0;
+    void *d_aux = nullptr;  // sort buffer and cell grid of whole-frame corner selection
+    size_t aux_bytes = 0;
     void *h_pin = nullptr;  // pinned host mirror of (part of) the work area: one DMA instead of one per array
     size_t pin_bytes = 0;
 
