@@ -149,6 +149,20 @@ int ktlvo_pyrlk_batch_dev(ktlvo_ctx *ctx, const int *prev_slots, const int *next
 int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi,
                       const ktlvo_gftt_params *params, float *xy, float *response, int *counts,
                       int cap_per_roi);
+/* The same detection for callers that must not allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc,
+ * hipFree or other allocating routine, copies nothing and does not synchronise: the ROI list travels as
+ * kernel arguments, the kernels' work memory is a fixed array inside the library (4 MiB + 8 KiB per GPU,
+ * held until the process ends) and the outputs are DEVICE arrays of the caller: d_xy [n_roi][cap][2],
+ * d_response [n_roi][cap], d_counts [n_roi], valid once the context's stream has been waited for.
+ * Limits: n_roi <= 192, ROI areas summing to <= 524288 pixels, every ROI <= 4096 pixels and <= 1024
+ * min-distance cells (the reference's 59 x 39 sub-regions are 2301 pixels); beyond them the call returns
+ * KTLVO_ERR_CAPACITY and enqueues nothing.  All calls on one GPU share the array: calls that overlap on
+ * one GPU (two streams, two contexts, two processes' worth of threads) race; calls in stream order do
+ * not, every call clears what it accumulates into. */
+int ktlvo_detect_gftt_noalloc(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi,
+                              const ktlvo_gftt_params *params, float *d_xy, float *d_response,
+                              int *d_counts, int cap_per_roi);
 /* Test hook: cornerHarris / cornerMinEigenVal response of one ROI (rw*rh floats). */
 int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *roi, int use_harris,
                           double harris_k, float *out);

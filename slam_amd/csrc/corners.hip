@@ -713,9 +713,63 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     return KTLVO_OK;
 }
 
+// ---- scratch of the allocation-free entry point -----------------------------------------------------------
+// ktlvo_detect_gftt_noalloc runs the same kernels as ktlvo_detect_gftt on a fixed device array instead of
+// the context's grown-on-demand work area.  Every GPU the library runs on holds its own copy of the array
+// (4 MiB + 8 KiB) until the process ends.  In host code the array's name is only a handle: its device
+// address is looked up once per context, with the context's device current (corner_noalloc_init, called by
+// ktlvo_create), and that address is what the kernels are given.
+constexpr int NOALLOC_MAX_ROIS = RoiTable::MAX;          // 192
+constexpr size_t NOALLOC_MAX_PIXELS = (size_t)512 << 10; // sum of the ROI areas of one call
+constexpr size_t NOALLOC_SCRATCH_BYTES = ((size_t)4 << 20) + ((size_t)8 << 10);
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+int corner_noalloc_init(ktlvo_ctx *ctx) {
+    void *ptr = nullptr;
+    KTLVO_HIP(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    ctx->noalloc_scratch = ptr;
+    return KTLVO_OK;
+}
+
 } // namespace ktlvo
 
 using namespace ktlvo;
+
+extern "C" int ktlvo_detect_gftt_noalloc(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois_in, int n_roi,
+                                         const ktlvo_gftt_params *p, float *d_xy, float *d_response, int *d_counts,
+                                         int cap) {
+    if (!ctx || !p || n_roi < 0 || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (n_roi == 0) return KTLVO_OK;
+    if (!rois_in || !d_xy || !d_response || !d_counts || cap <= 0) return KTLVO_ERR_INVALID;
+    if (p->block_size != 3) return KTLVO_ERR_UNSUPPORTED;
+    if (p->max_corners > cap) return KTLVO_ERR_INVALID;
+    if (!(p->quality > 0) || !(p->min_dist >= 0)) return KTLVO_ERR_INVALID;
+    if (ctx->built[slot] < 0) return KTLVO_ERR_STATE;
+    if (!ctx->noalloc_scratch) return KTLVO_ERR_STATE;
+    if (n_roi > NOALLOC_MAX_ROIS) {
+        ctx->last_error = "ktlvo_detect_gftt_noalloc: more than 192 ROIs";
+        return KTLVO_ERR_CAPACITY;
+    }
+    RoiDev rois[NOALLOC_MAX_ROIS];
+    size_t total;
+    int maxw, maxh;
+    int rc = check_rois(ctx, rois_in, n_roi, rois, total, maxw, maxh);
+    if (rc != KTLVO_OK) return rc;
+    if (total > NOALLOC_MAX_PIXELS || corner_scratch_bytes(n_roi, total) > NOALLOC_SCRATCH_BYTES) {
+        ctx->last_error = "ktlvo_detect_gftt_noalloc: ROI areas sum to more than 524288 pixels";
+        return KTLVO_ERR_CAPACITY;
+    }
+    if (!rois_fit_lds(rois, n_roi, p->min_dist) || !rois_fit_table(rois, n_roi)) {
+        ctx->last_error = "ktlvo_detect_gftt_noalloc: an ROI exceeds 4096 pixels or 1024 min-distance cells";
+        return KTLVO_ERR_CAPACITY;
+    }
+    CornerScratch s;
+    corner_scratch_carve(ctx->noalloc_scratch, n_roi, total, s);
+    // corner_setup clears the counters the kernels accumulate into; the candidate keys of an earlier call
+    // are dead (each ROI reads only the first cand_cnt keys, which this call writes)
+    return corner_detect_small_dev(ctx, slot, rois, n_roi, maxw, maxh, p, s, d_xy, d_response, d_counts, cap);
+}
 
 extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *roi, int use_harris, double harris_k,
                                      float *out) {

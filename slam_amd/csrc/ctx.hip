@@ -166,6 +166,7 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
     ok = ok && hipMalloc((void **)&ctx->d_status, 2 * np) == hipSuccess; // two lists: batched stereo/temporal LK
     ok = ok && hipMalloc((void **)&ctx->d_err, 2 * np * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_idx, (np + 1) * sizeof(int)) == hipSuccess;
+    ok = ok && corner_noalloc_init(ctx) == KTLVO_OK;
     if (!ok) {
         fprintf(stderr, "ktlvo_create: device allocation failed: %s\n", hipGetErrorString(hipGetLastError()));
         ktlvo_destroy(ctx);

@@ -86,6 +86,7 @@ struct ktlvo_ctx {
     int *d_idx = nullptr;   // max_points + 1 ints
     void *d_misc = nullptr; // corner / ransac work area
     size_t misc_bytes = 0;
+    void *noalloc_scratch = nullptr; // this device's address of the fixed scratch array of ktlvo_detect_gftt_noalloc
     void *d_aux = nullptr;  // sort buffer and cell grid of whole-frame corner selection
     size_t aux_bytes = 0;
     void *h_pin = nullptr;  // pinned host mirror of (part of) the work area: one DMA instead of one per array
@@ -120,6 +121,7 @@ struct ProfScope {
     ~ProfScope();
 };
 
+int corner_noalloc_init(ktlvo_ctx *ctx); // corners.hip
 int ensure_misc(ktlvo_ctx *ctx, size_t bytes);
 int ensure_pin(ktlvo_ctx *ctx, size_t bytes);
 inline bool slot_ok(const ktlvo_ctx *ctx, int s) { return s >= 0 && s < ctx->cfg.num_slots; }

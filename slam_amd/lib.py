@@ -92,6 +92,7 @@ SIGNATURES = {
     "ktlvo_pyrlk_dev": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, C.POINTER(LkParams)]),
     "ktlvo_pyrlk_batch_dev": (_i, [_vp, _ip, _ip, _i, _vp, _i, _vp, _vp, _vp, C.POINTER(LkParams)]),
     "ktlvo_detect_gftt": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
+    "ktlvo_detect_gftt_noalloc": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_corner_response": (_i, [_vp, _i, C.POINTER(Roi), _i, _d, _vp]),
     "ktlvo_anms": (_i, [_vp, _vp, _vp, _ip, _i]),
     "ktlvo_fb_gate": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _ip]),
@@ -325,6 +326,13 @@ class Context:
         self._chk(lib.ktlvo_detect_gftt(self._h, slot, arr, n, C.byref(params), _ptr(xy), _ptr(resp), _ptr(counts),
                                         cap), "ktlvo_detect_gftt")
         return [(xy[i, :counts[i]].copy(), resp[i, :counts[i]].copy()) for i in range(n)]
+
+    def detect_gftt_noalloc(self, slot, rois, params, d_xy, d_resp, d_counts, cap):
+        """Device-pointer form that allocates nothing; returns the status code (no exception) so that tests
+        can probe its limits.  Outputs are valid after sync()."""
+        n = len(rois)
+        arr = (Roi * max(n, 1))(*[Roi(*r) for r in rois])
+        return lib.ktlvo_detect_gftt_noalloc(self._h, slot, arr, n, C.byref(params), d_xy, d_resp, d_counts, cap)
 
     def anms(self, xy, resp, num_to_keep):
         xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2).copy()
