@@ -400,29 +400,33 @@ struct SelLargeArgs {
     int w, h;
     double min_dist;
     int cell, gw, gh;
-    int *cell_cnt;      // gw * gh, cleared
-    unsigned *cell_pts; // gw * gh * 4: x | y << 16
+    int *cell_cnt;   // gw * gh, cleared
+    uint4 *cell_pts; // gw * gh: up to four accepted corners as x | y << 16, empty places 0xFFFFFFFF
     int limit;
     float *xy, *resp;
     int *count;
     int *overflow;
 };
-constexpr int CH = 512; // candidates per chunk of the greedy pass
+constexpr int CH = 512;  // candidates per chunk of the greedy pass
+constexpr int HT = 2048; // chunk-local hash of the survivors' cells (load factor <= 1/4)
 
 // goodFeaturesToTrack's greedy pass: walk the candidates in sorted order and accept one unless an accepted
 // corner lies closer than min_dist.  A candidate's fate depends only on the accepted corners ranked before
 // it, so a chunk of CH consecutive candidates is handled in parallel: (1) every candidate is tested
 // against the corners accepted from earlier chunks (cell grid in global memory, owned by this single
-// workgroup); (2) the survivors are compacted in rank order and each finds the survivors ranked before it
-// that are too close (a bit mask per survivor); (3) rounds in which a survivor with an accepted
-// predecessor in its mask is rejected, and one whose predecessors are all rejected is accepted, until all
-// are decided -- the lowest undecided survivor always decides, and chains are short because a chunk's
-// candidates are scattered over the frame; (4) the accepted ones take their output places in rank order
-// and enter the grid.
+// workgroup; the nine cells around a candidate are nine independent 16-byte loads); (2) the survivors are
+// compacted in rank order, entered into a hash of their cells in LDS, and each finds, in the nine cells
+// around it, the survivors ranked before it that are too close (a bit mask per survivor); (3) rounds in
+// which a survivor with an accepted predecessor in its mask is rejected, and one whose predecessors are
+// all rejected is accepted, until all are decided -- the lowest undecided survivor always decides, and
+// chains are short because a chunk's candidates are scattered over the frame; (4) the accepted ones take
+// their output places in rank order and enter the grid.
 __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     __shared__ unsigned long long s_key[CH];
     __shared__ int s_x[CH], s_y[CH];
     __shared__ unsigned conf[CH][CH / 32];
+    __shared__ unsigned ht_key[HT]; // cell index + 1, 0 = empty
+    __shared__ unsigned short ht_val[HT];
     __shared__ unsigned accm[CH / 32], rejm[CH / 32];
     __shared__ int wave_off[CH / 64 + 1];
     __shared__ int s_total;
@@ -430,32 +434,39 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     const int n = *a.n_ptr;
     const float md = (float)a.min_dist;
     const double md2 = a.min_dist * a.min_dist;
+    auto too_close = [&](int x, int y, unsigned p) {
+        const float dx = (float)x - (float)(p & 0xffff), dy = (float)y - (float)(p >> 16);
+        return (double)(dx * dx + dy * dy) < md2;
+    };
     if (tid == 0) s_total = 0;
     __syncthreads();
     for (int base = 0; base < n; base += CH) {
         const int total0 = s_total;
         if (total0 >= a.limit) break;
+        // what the previous chunk stored must be read from L2, not from this CU's L1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int q = tid; q < HT; q += CH) ht_key[q] = 0u;
         // (1) against the grid
         const int i = base + tid;
         unsigned long long key = 0;
-        int x = 0, y = 0;
+        int x = 0, y = 0, xc = 0, yc = 0;
         bool surv = false;
         if (i < n) {
             key = a.keys[i];
             const unsigned idx = (unsigned)key;
             y = idx / a.w; x = idx - y * a.w;
-            const int xc = x / a.cell, yc = y / a.cell;
-            surv = true;
-            for (int cy = max(yc - 1, 0); cy <= min(yc + 1, a.gh - 1) && surv; cy++)
-                for (int cx = max(xc - 1, 0); cx <= min(xc + 1, a.gw - 1) && surv; cx++) {
-                    const int ci = cy * a.gw + cx;
-                    const int cnt = min(__hip_atomic_load(&a.cell_cnt[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 4);
-                    for (int s = 0; s < cnt; s++) {
-                        const unsigned p = __hip_atomic_load(&a.cell_pts[4 * ci + s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const float dx = (float)x - (float)(p & 0xffff), dy = (float)y - (float)(p >> 16);
-                        if ((double)(dx * dx + dy * dy) < md2) { surv = false; break; }
-                    }
-                }
+            xc = x / a.cell; yc = y / a.cell;
+            uint4 c[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) { // cells off the grid are read as their clamped neighbour: a harmless repeat
+                const int cx = min(max(xc + q % 3 - 1, 0), a.gw - 1), cy = min(max(yc + q / 3 - 1, 0), a.gh - 1);
+                c[q] = a.cell_pts[cy * a.gw + cx];
+            }
+            bool hit = false;
+#pragma unroll
+            for (int q = 0; q < 9; q++)
+                hit = hit || too_close(x, y, c[q].x) || too_close(x, y, c[q].y) || too_close(x, y, c[q].z) || too_close(x, y, c[q].w);
+            surv = !hit;
         }
         // (2) survivors in rank order
         const unsigned long long vote = __ballot(surv);
@@ -471,20 +482,36 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         if (surv) {
             const int p = wave_off[wave] + __popcll(vote & ((1ull << lane) - 1ull));
             s_key[p] = key; s_x[p] = x; s_y[p] = y;
+            // several survivors of one cell take several places: the probe for a cell walks to the first empty place
+            const unsigned ck = (unsigned)(yc * a.gw + xc) + 1u;
+            unsigned hsh = (ck * 2654435761u) >> 21; // 11 bits
+            while (atomicCAS(&ht_key[hsh], 0u, ck) != 0u) hsh = (hsh + 1) & (HT - 1);
+            ht_val[hsh] = (unsigned short)p;
         }
         __syncthreads();
         // survivor `tid` against the survivors ranked before it
         int state = 3; // 0 undecided, 1 accepted, 2 rejected, 3 not a survivor
         if (tid < S) {
             const int mx = s_x[tid], my = s_y[tid];
-            unsigned word = 0, any = 0;
-            for (int q = 0; q < tid; q++) {
-                const float dx = (float)(mx - s_x[q]), dy = (float)(my - s_y[q]);
-                if (fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2) word |= 1u << (q & 31);
-                if ((q & 31) == 31) { conf[tid][q >> 5] = word; any |= word; word = 0; }
-            }
-            any |= word;
-            for (int wq = tid >> 5; wq < CH / 32; wq++) { conf[tid][wq] = word; word = 0; }
+            const int mxc = mx / a.cell, myc = my / a.cell;
+            for (int wq = 0; wq < CH / 32; wq++) conf[tid][wq] = 0u;
+            bool any = false;
+            for (int cy = max(myc - 1, 0); cy <= min(myc + 1, a.gh - 1); cy++)
+                for (int cx = max(mxc - 1, 0); cx <= min(mxc + 1, a.gw - 1); cx++) {
+                    const unsigned ck = (unsigned)(cy * a.gw + cx) + 1u;
+                    for (unsigned hsh = (ck * 2654435761u) >> 21;; hsh = (hsh + 1) & (HT - 1)) {
+                        const unsigned kk = ht_key[hsh];
+                        if (kk == 0u) break;
+                        if (kk != ck) continue;
+                        const int q = ht_val[hsh];
+                        if (q >= tid) continue;
+                        const float dx = (float)(mx - s_x[q]), dy = (float)(my - s_y[q]);
+                        if (fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2) {
+                            conf[tid][q >> 5] |= 1u << (q & 31);
+                            any = true;
+                        }
+                    }
+                }
             state = any ? 0 : 1;
         }
         // (3) rounds
@@ -525,12 +552,11 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                 a.resp[pos] = ord2f((unsigned)(s_key[tid] >> 32));
                 const int ci = (my / a.cell) * a.gw + (mx / a.cell);
                 const int slot = atomicAdd(&a.cell_cnt[ci], 1);
-                if (slot < 4) __hip_atomic_store(&a.cell_pts[4 * ci + slot], (unsigned)mx | ((unsigned)my << 16), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < 4) ((unsigned *)&a.cell_pts[ci])[slot] = (unsigned)mx | ((unsigned)my << 16);
                 else *a.overflow = 2; // cannot happen for cell = round(min_dist); reported instead of dropped
             }
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
     }
     if (tid == 0) *a.count = s_total;
@@ -683,8 +709,10 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    // keys and counter cleared in one go (the sort runs over all np2 keys; zeros sort last), then the grid
+    // keys, counter and the cells' counts cleared in one go (the sort runs over all np2 keys; zeros sort last);
+    // empty places of the cells hold a far-away point
     KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc + (dist ? up((size_t)gw * gh * 4) : 0), ctx->stream));
+    if (dist) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)gw * gh * 16, ctx->stream));
     const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
     hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
                        p->quality, d_keys, d_n);
@@ -705,7 +733,7 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     } else {
         SelLargeArgs a;
         a.keys = d_keys; a.n_ptr = d_n; a.w = R.w; a.h = R.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh;
-        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (unsigned *)(b + o_cp); a.limit = limit;
+        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
         a.xy = d_xy; a.resp = d_resp; a.count = d_count; a.overflow = s.d_overflow;
         hipLaunchKernelGGL(corner_select_large, dim3(1), dim3(CH), 0, ctx->stream, a);
     }

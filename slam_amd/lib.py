@@ -122,6 +122,8 @@ def _load():
                           "There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if not hasattr(lib, name) and os.environ.get("KTLVO_AB_OLD_LIBRARY") == "1":
+            continue  # A/B timing tools load an older build of the library in place of the current one
         fn = getattr(lib, name)  # AttributeError here means the library is stale
         fn.restype = res
         fn.argtypes = args
