@@ -94,6 +94,8 @@ _lib.orc_solve_p3p4.argtypes = [_f64p, _f64p, _f64p, _f64p, _f64p]
 _lib.orc_gao_quartic.argtypes = [C.c_double] * 5 + [_f64p]
 _lib.orc_gao_quartic.restype = None
 _lib.orc_roots4.argtypes = [_f64p, _f64p]
+_lib.orc_set_lk_sum_mode.argtypes = [C.c_int]
+_lib.orc_set_lk_sum_mode.restype = None
 _lib.orc_p3p_set_polish.argtypes = [C.c_int]
 _lib.orc_p3p_set_polish.restype = None
 _lib.orc_project_score.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, C.c_float, C.c_void_p, C.c_void_p]
@@ -291,6 +293,11 @@ def gao_quartic(a, b, p, q, r):
     c = np.zeros(5, np.float64)
     _lib.orc_gao_quartic(a, b, p, q, r, c)
     return c
+
+
+def set_lk_sum_mode(mode):
+    """0 serial (default), 1 four-lane, 2 pairwise: order of the float additions in the LK window sums."""
+    _lib.orc_set_lk_sum_mode(int(mode))
 
 
 def p3p_set_polish(newton_steps):

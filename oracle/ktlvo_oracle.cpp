@@ -168,9 +168,42 @@ static uint8_t *g_iter_log = nullptr; /* optional diagnostics: iterations per (l
 static int g_iter_log_n = 0;
 extern "C" void orc_set_iter_log(uint8_t *buf, int n_points) { g_iter_log = buf; g_iter_log_n = n_points; }
 
+/* Order in which the 441 float terms of each window sum are added.  0: one accumulator, raster order
+ * (LKTrackerInvoker's scalar path; the oracle's reference behaviour).  1: four accumulators taken in turn
+ * along a row and added at the end, the way a 4-lane SIMD build accumulates.  2: pairwise (tree) sum.
+ * Modes 1 and 2 exist to measure how far the RESULT moves when only the rounding order of these sums
+ * changes; every integer term is the same in all modes. */
+static int g_lk_sum_mode = 0;
+extern "C" void orc_set_lk_sum_mode(int mode) { g_lk_sum_mode = mode < 0 || mode > 2 ? 0 : mode; }
+
 namespace {
 
+/* accumulator for one window sum under sum mode MODE */
+template <int MODE>
+struct WinSum {
+    float lane[4] = {0, 0, 0, 0};
+    float terms[32 * 32];
+    int n = 0;
+    inline void add(float v, int x) {
+        if (MODE == 0) lane[0] += v;
+        else if (MODE == 1) lane[x & 3] += v;
+        else terms[n++] = v;
+    }
+    static float tree(const float *t, int n) {
+        if (n == 1) return t[0];
+        if (n == 2) return t[0] + t[1];
+        const int h = n / 2;
+        return tree(t, h) + tree(t + h, n - h);
+    }
+    inline float total() const {
+        if (MODE == 0) return lane[0];
+        if (MODE == 1) return (lane[0] + lane[2]) + (lane[1] + lane[3]);
+        return n ? tree(terms, n) : 0.f;
+    }
+};
+
 /* LKTrackerInvoker::operator() (scalar path: float accumulators) for points [i0,i1) of one level. */
+template <int MODE>
 void lk_level_range(const Level &I, const Level &J, const float *prevPts, float *nextPts, uint8_t *status,
                     float *err, int level, int maxLevel, int win, int maxCount, double epsSq,
                     double minEigThr, int i0, int i1) {
@@ -201,7 +234,7 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
         int iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
-        float iA11 = 0, iA12 = 0, iA22 = 0;
+        WinSum<MODE> sA11, sA12, sA22;
         for (int y = 0; y < win; y++) {
             const uint8_t *src = I.ipx(ipx, ipy + y);
             const int16_t *dsrc = I.dpx(ipx, ipy + y);
@@ -217,11 +250,12 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
                 Ip[x] = (int16_t)ival;
                 dIp[0] = (int16_t)ixval;
                 dIp[1] = (int16_t)iyval;
-                iA11 += (float)(ixval * ixval);
-                iA12 += (float)(ixval * iyval);
-                iA22 += (float)(iyval * iyval);
+                sA11.add((float)(ixval * ixval), x);
+                sA12.add((float)(ixval * iyval), x);
+                sA22.add((float)(iyval * iyval), x);
             }
         }
+        const float iA11 = sA11.total(), iA12 = sA12.total(), iA22 = sA22.total();
         float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
@@ -246,7 +280,7 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
             iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
             iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            float ib1 = 0, ib2 = 0;
+            WinSum<MODE> sb1, sb2;
             for (int y = 0; y < win; y++) {
                 const uint8_t *Jp = J.ipx(inx, iny + y);
                 const int16_t *Ip = &Ibuf[(size_t)y * win];
@@ -254,10 +288,11 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
                 for (int x = 0; x < win; x++, dIp += 2) {
                     int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 +
                                        Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
-                    ib1 += (float)(diff * dIp[0]);
-                    ib2 += (float)(diff * dIp[1]);
+                    sb1.add((float)(diff * dIp[0]), x);
+                    sb2.add((float)(diff * dIp[1]), x);
                 }
             }
+            const float ib1 = sb1.total(), ib2 = sb2.total();
             float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
             float dx = (float)((A12 * b2 - A22 * b1) * D);
             float dy = (float)((A12 * b1 - A11 * b2) * D);
@@ -285,16 +320,17 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
             iw01 = cv_round(aa * (1.f - bb) * (1 << W_BITS));
             iw10 = cv_round((1.f - aa) * bb * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            float errval = 0.f;
+            WinSum<MODE> serr;
             for (int y = 0; y < win; y++) {
                 const uint8_t *Jp = J.ipx(inx, iny + y);
                 const int16_t *Ip = &Ibuf[(size_t)y * win];
                 for (int x = 0; x < win; x++) {
                     int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 +
                                        Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
-                    errval += std::abs((float)diff);
+                    serr.add(std::abs((float)diff), x);
                 }
             }
+            const float errval = serr.total();
             err[pt] = errval * 1.f / (32 * win * win);
         }
     }
@@ -314,20 +350,21 @@ extern "C" int orc_pyrlk(const orc_pyramid *prev, const orc_pyramid *next, const
     const double epsSq = epsilon * epsilon;
     for (int i = 0; i < n; i++) { status[i] = 1; err[i] = 0; }
     nthreads = std::max(1, std::min(nthreads, n));
+    if (win > 32) return -2; /* WinSum's term buffer */
+    auto range_fn = g_lk_sum_mode == 1 ? lk_level_range<1> : g_lk_sum_mode == 2 ? lk_level_range<2> : lk_level_range<0>;
     for (int level = maxLevel; level >= 0; level--) {
         const Level &I = prev->levels[level];
         const Level &J = next->levels[level];
         if (I.w != J.w || I.h != J.h) return -3;
         if (nthreads == 1) {
-            lk_level_range(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count, epsSq,
-                           min_eig_thr, 0, n);
+            range_fn(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count, epsSq, min_eig_thr, 0, n);
         } else {
             std::vector<std::thread> th;
             for (int t = 0; t < nthreads; t++) {
                 int i0 = (int)((long long)n * t / nthreads), i1 = (int)((long long)n * (t + 1) / nthreads);
                 th.emplace_back([&, i0, i1]() {
-                    lk_level_range(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count,
-                                   epsSq, min_eig_thr, i0, i1);
+                    range_fn(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count, epsSq, min_eig_thr,
+                             i0, i1);
                 });
             }
             for (auto &t : th) t.join();

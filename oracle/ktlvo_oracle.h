@@ -42,6 +42,11 @@ int orc_pyramid_level_size(const orc_pyramid *p, int level, int *w, int *h);
 int orc_pyramid_level_copy(const orc_pyramid *p, int level, uint8_t *dst);
 int orc_pyramid_deriv_copy(const orc_pyramid *p, int level, int16_t *dst /* 2*w*h */);
 
+/* Order of the float additions inside orc_pyrlk's window sums (process-wide): 0 = one accumulator in
+ * raster order (default; LKTrackerInvoker's scalar path), 1 = four accumulators in turn along a row (a
+ * 4-lane SIMD build), 2 = pairwise.  For measuring the sensitivity of LK results to rounding order. */
+void orc_set_lk_sum_mode(int mode);
+
 /* cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(win,win), maxLevel,
  * TermCriteria(COUNT|EPS, max_count, epsilon), flags=0, minEigThreshold).
  * featureTracking.cpp:205-209.  epsilon is the TermCriteria value (0.01); it is squared

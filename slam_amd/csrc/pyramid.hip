@@ -33,6 +33,9 @@ typedef __attribute__((address_space(1))) uint8_t *gbyte;
 typedef const __attribute__((address_space(1))) uint8_t *gcbyte;
 typedef __attribute__((address_space(1))) uint32_t *gword;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// the same sixteen bytes at an address that is only dword aligned (rows start at x - 4 for any x that is a
+// multiple of 4): global_load_dwordx4 takes such addresses, and the type says so to the compiler
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 
 constexpr int PD_ROWS = 4;         // output rows per thread
 constexpr int PD_TW = 256;         // output columns per workgroup (64 lanes x 4 pixels)
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotLi
     for (int r = 0; r < NS; r++) {
         int sy = 2 * oy0 - 2 + r;
         sy = sy < last_row ? sy : last_row;
-        const u32x4 d = *(const __attribute__((address_space(1))) u32x4 *)((gcbyte)src.origin + (ptrdiff_t)sy * src.pitch + 2 * ox - 4);
+        const u32x4 d = *(const __attribute__((address_space(1))) u32x4_a4 *)((gcbyte)src.origin + (ptrdiff_t)sy * src.pitch + 2 * ox - 4);
         pyr_h4(d, h01[r], h23[r]);
     }
     const u16x2 six = {6, 6}, four = {4, 4}, half = {128, 128};
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
     u32x4 r[3];
 #pragma unroll
     for (int j = 0; j < 3; j++)
-        r[j] = *(const __attribute__((address_space(1))) u32x4 *)((gcbyte)L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
+        r[j] = *(const __attribute__((address_space(1))) u32x4_a4 *)((gcbyte)L.origin + (ptrdiff_t)(y - 1 + j) * L.pitch + x0 - 4);
     auto pr = [](uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_bit_cast(i16x2, __builtin_amdgcn_perm(hi, lo, sel)); };
     // pairs (b[3+2j], b[4+2j]), j = 0..4, and (b[4+2j], b[5+2j]), j = 0..3, zero-extended
     auto odd = [&](const u32x4 &d, i16x2 (&o)[5]) {

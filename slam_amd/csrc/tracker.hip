@@ -80,15 +80,26 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         if ((rc = ktlvo_upload_image(ctx, t->sCurR, right, W, H, W)) != KTLVO_OK) return rc;
         const int s[2] = {t->sCurL, t->sCurR};
         if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
+        // the caller may reuse (pinned) frame buffers as soon as this call returns
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         t->inited = true;
         return KTLVO_OK;
     }
-    std::swap(t->sLastL, t->sCurL); // :361-365: last <- cur, then the new frame becomes cur
-    std::swap(t->sLastR, t->sCurR);
-    if ((rc = ktlvo_upload_image(ctx, t->sCurL, left, W, H, W)) != KTLVO_OK) return rc;
-    if ((rc = ktlvo_upload_image(ctx, t->sCurR, right, W, H, W)) != KTLVO_OK) return rc;
+    // :361-365: last <- cur, then the new frame becomes cur.  The new roles and the new track list live in
+    // locals until the frame's device work has succeeded (commit below): a call that fails on the way leaves
+    // the tracker as it was -- the previous frame still "cur", its track list intact -- so the failed frame
+    // is dropped instead of silently restarting the track ids.  (The slots the new images go into held the
+    // frame before the previous one, which nothing refers to any more.)
+    const int sLL = t->sCurL, sLR = t->sCurR, sCL = t->sLastL, sCR = t->sLastR;
+    std::vector<ktlvo_image_point> newPointsCur;
+    auto commit = [&]() {
+        t->sLastL = sLL; t->sLastR = sLR; t->sCurL = sCL; t->sCurR = sCR;
+        t->imagePointsCur.swap(newPointsCur);
+    };
+    if ((rc = ktlvo_upload_image(ctx, sCL, left, W, H, W)) != KTLVO_OK) return rc;
+    if ((rc = ktlvo_upload_image(ctx, sCR, right, W, H, W)) != KTLVO_OK) return rc;
     {
-        const int s[2] = {t->sCurL, t->sCurR};
+        const int s[2] = {sCL, sCR};
         if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
     }
 
@@ -100,7 +111,6 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         featuresLastLeft.push_back(p.v);
         featuresLastLeftIndeces.push_back(p.ind);
     }
-    t->imagePointsCur.clear();
 
     bool newKeyFrame = false;
     if ((int)featuresLastLeftIndeces.size() < c.keyframe_min_tracked) { // :406-441
@@ -116,7 +126,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         std::vector<float> xy((size_t)n_roi * capr * 2), resp((size_t)n_roi * capr);
         std::vector<int> counts(n_roi);
         const ktlvo_gftt_params gp = {capr, 0.01, 10, 3, 1, 0.0}; // GFTTDetector::create(100,0.01,10,3,true,0.0), :103
-        rc = ktlvo_detect_gftt(ctx, t->sLastL, rois.data(), n_roi, &gp, xy.data(), resp.data(), counts.data(), capr);
+        rc = ktlvo_detect_gftt(ctx, sLL, rois.data(), n_roi, &gp, xy.data(), resp.data(), counts.data(), capr);
         if (rc != KTLVO_OK) return rc;
         std::vector<float> kxy, kresp;
         for (int r = 0; r < n_roi; r++)
@@ -135,8 +145,12 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     if (new_key_frame) *new_key_frame = newKeyFrame ? 1 : 0;
 
     const int N = (int)(featuresLastLeft.size() / 2);
-    if (N == 0) return KTLVO_OK;
     if (N > c.max_points) return KTLVO_ERR_CAPACITY;
+    if (N == 0) { // nothing to track: the uploads still have to finish before the caller's buffers are free again
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        commit();
+        return KTLVO_OK;
+    }
     const int CAP = c.max_points;
     typedef TrackerState TS;
     float *dA = t->list(TS::A, CAP), *dBC = t->list(TS::BC, CAP), *dDE = t->list(TS::DE, CAP);
@@ -146,7 +160,6 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     int *dCnt = t->d_out, *dK1 = dCnt + 8, *dK2 = dK1 + N, *dK3 = dK2 + N;
     float *dU1 = (float *)(dK3 + N), *dU2 = dU1 + 2 * (size_t)N, *dU3 = dU2 + 2 * (size_t)N;
     const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4}; // :195-197, :208-209
-    const int sLL = t->sLastL, sLR = t->sLastR, sCL = t->sCurL, sCR = t->sCurR;
 
     // The reference makes 8 LK calls per frame.  A point's track depends on nothing but its two images
     // and its start, so the two forward calls inside getOpticalFlow (:205) repeat, on a subset, what
@@ -208,7 +221,6 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     const int *cnt = t->h_io, *K1 = cnt + 8, *K2 = K1 + N, *K3 = K2 + N;
     const float *U1 = (const float *)(K3 + N), *U2 = U1 + 2 * (size_t)N, *U3 = U2 + 2 * (size_t)N;
     const int n3 = cnt[2];
-    if (n3 == 0) return KTLVO_OK;
 
     // :526-573 disparity -> depth and output assembly
     int nout = 0;
@@ -220,7 +232,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         int ind = i;
         if (!newKeyFrame) ind = featuresLastLeftIndeces[K1[K2[K3[i]]]]; // curLeftIndeces[i]
         ktlvo_image_point ip = {U2[2 * i], U2[2 * i + 1], ind};
-        t->imagePointsCur.push_back(ip);
+        newPointsCur.push_back(ip);
         if (nout < cap) {
             ktlvo_depth_point dp = {U1[2 * i], U1[2 * i + 1], depth, 0, ind, newKeyFrame ? 1 : 0};
             last[nout] = dp;
@@ -228,6 +240,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         }
         ++nout;
     }
+    commit(); // the frame is done; output arrays that are too small do not undo it
     *n_out = nout < cap ? nout : cap;
     return nout <= cap ? KTLVO_OK : KTLVO_ERR_CAPACITY;
 }

@@ -65,6 +65,22 @@ def main():
     r = O.solve_pnp_ransac(Xw, uv, K)
     np.savez_compressed(os.path.join(OUT, "ransac_400.npz"), X3=Xw, x2=uv, K=K, rvec=r["rvec"], tvec=r["tvec"],
                         mask=r["mask"], n_inliers=np.int32(r["n_inliers"]), iters=np.int32(r["iters"]), log=r["log"])
+    # 5. inputs only: the frame of the randomised sweep (tests/test_gpu_fuzz.py, seed 1111, 240 cases, case 176:
+    #    164x140 white noise with saturated patches, shifted by whole pixels) on which LK results are most
+    #    sensitive to the order of the float additions
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_fuzz as T
+    rng = np.random.default_rng(1111)
+    for i, (w, h) in enumerate(T._sizes(rng, 240)):
+        a, b = T._images(rng, w, h, i % 3)
+        pts = np.stack([rng.uniform(-30, w + 30, 600), rng.uniform(-30, h + 30, 600)], 1).astype(np.float32)
+        pts[:8] = [[0, 0], [w - 1, h - 1], [w, h], [-21, -21], [w - 0.5, 0.25], [0.25, h - 0.5], [w / 2, h / 2],
+                   [10.5, 10.5]]
+        if i == 176:
+            assert (w, h) == (164, 140)
+            np.savez_compressed(os.path.join(OUT, "lk_noise_164x140.npz"), prev=np.ascontiguousarray(a),
+                                next=np.ascontiguousarray(b), pts=pts)
+            break
     print("golden vectors written to", OUT)
 
 
