@@ -99,10 +99,14 @@ def parse():
                     help="kernels bracketed by HIP events inside the timed region: the dominant one (default; the "
                          "pyramid kernels are then timed in an untimed pass) or all three")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
-    ap.add_argument("--workload", choices=["pairs", "sequence", "ransac"], default="pairs",
+    ap.add_argument("--workload", choices=["pairs", "sequence", "ransac", "batch"], default="pairs",
                     help="pairs: the headline frame-pair stream (default); sequence: stereo tracker + pose on a "
                          "synthetic sequence per rank, trajectories gathered (BASELINE configs[0]/[3]); ransac: "
-                         "batched hypothesis scoring, 1024 hypotheses x 8000 points (configs[2])")
+                         "batched hypothesis scoring, 1024 hypotheses x 8000 points (configs[2]); batch: a FIXED "
+                         "batch of independent frame pairs sharded round-robin over the ranks (configs[4]: 64 pairs "
+                         "of 3840x2160 frames, 16384 corners; strong scaling)")
+    ap.add_argument("--batch-pairs", type=int, default=64, help="batch workload: frame pairs in the whole job")
+    ap.add_argument("--dump-pairs", default="", help="batch workload: rank 0 saves the per-pair result table here (.npy)")
     ap.add_argument("--frames", type=int, default=20, help="sequence workload: stereo frames per rank")
     ap.add_argument("--rank-offset", type=int, default=0,
                     help="sequence workload: added to the rank when choosing its sequence (lets one GPU replay rank r's input)")
@@ -147,7 +151,7 @@ def run_sequence(a, rank, world, local, dev):
     for c in ctxs:
         c.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     t0 = time.perf_counter()
     if S == 1:
@@ -250,6 +254,110 @@ def run_ransac(a, rank, world, local, dev):
     ctx.close()
 
 
+def run_batch(a, rank, world, local, dev):
+    """BASELINE configs[4]: a fixed batch of independent frame pairs (pair p = frames 0 and 1 of the corridor
+    with seed 0x5EED0100 + p), sharded round-robin by pair index; every rank builds the pyramids of its pairs
+    and tracks them in one LK launch per step.  Total work is fixed, so this is strong scaling.  The per-pair
+    results (tracked count, CRC-32 of the status bytes and of the tracked positions) are gathered with one
+    all_gather and are the same table whatever the number of ranks."""
+    import zlib
+    W, H, NF, NB = a.width, a.height, a.features, a.batch_pairs
+    mine = shard.shard_round_robin(NB, rank, world)
+    n_loc = len(mine)
+    assert n_loc <= 256
+    pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
+    frames = []
+    for p in mine:
+        frames += synth.render_corridor_frames(W, H, (0x5EED0100 + p) & 0xFFFFFFFF, 2, workers=2)
+    cfg = K.default_config(width=W, height=H, num_slots=max(2 * n_loc, 1), max_level=a.max_level,
+                           max_points=max(NF, 1024), cx=601.8873 + (W - 1242) * 0.5, cy=183.1104 + (H - 375) * 0.5)
+    ctx = K.Context(cfg, device=local)
+    for s, f in enumerate(frames):
+        ctx.upload_image(s, f)
+    ctx.sync()
+    slots = list(range(2 * n_loc))
+    prev_slots, next_slots = slots[0::2], slots[1::2]
+    pts = np.zeros((max(n_loc, 1), NF, 2), np.float32)
+    for j, s in enumerate(prev_slots):
+        md = a.min_dist
+        (xy, _), = ctx.detect_gftt(s, [(0, 0, W, H)], K.gftt_params(NF, 0.01, md, 3, 0, 0.0))
+        while len(xy) < NF:   # a frame short of corners at this spacing: tighten it (deterministic per pair)
+            md *= 0.9
+            if md < 1.0:
+                raise SystemExit("pair %d yields %d corners < %d even at minDistance 1" % (mine[j], len(xy), NF))
+            (xy, _), = ctx.detect_gftt(s, [(0, 0, W, H)], K.gftt_params(NF, 0.01, md, 3, 0, 0.0))
+        pts[j] = xy
+    d_prev = torch.from_numpy(pts).to(dev)
+    d_next = torch.zeros_like(d_prev)
+    d_status = torch.zeros((max(n_loc, 1), NF), dtype=torch.uint8, device=dev)
+    d_err = torch.zeros((max(n_loc, 1), NF), dtype=torch.float32, device=dev)
+    lk = K.lk_params(WIN, a.max_level)
+
+    def step():
+        if n_loc:
+            ctx.build_pyramids(slots)
+            ctx.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, d_next.data_ptr(), d_status.data_ptr(),
+                                d_err.data_ptr(), lk)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    fence()
+    ctx.profile_enable(2 << K.K_PYRLK)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k3_ms, k3_n = ctx.profile_get(K.K_PYRLK)
+    ctx.profile_enable(False)
+    st, nx = d_status.cpu().numpy(), d_next.cpu().numpy()
+    rows = np.zeros((n_loc, len(shard.PAIR_FIELDS)), np.int64)
+    for j, p in enumerate(mine):
+        ok = st[j] == 1
+        rows[j] = (p, NF, int(ok.sum()), zlib.crc32(st[j].tobytes()), zlib.crc32(nx[j][ok].tobytes()))
+    table = shard.gather_pair_records(torch.from_numpy(rows).to(dev), NB, world)
+    t_max = shard.max_over_ranks(elapsed, dev, world)
+    rec = torch.tensor([float(n_loc * NF), float(rows[:, 2].sum()), float(n_loc), k3_ms, float(k3_n), 0.0, 0.0, elapsed],
+                       dtype=torch.float64, device=dev)
+    recs = shard.gather_records(rec, world)
+    if rank == 0:
+        if a.dump_pairs:
+            np.save(a.dump_pairs, table)
+        tracked = int(table[:, 2].sum())
+        bpf = lk_bytes_per_feature(levels)
+        k3_avg_s = max(float(r[3]) / max(float(r[4]), 1.0) for r in recs.tolist()) * 1e-3   # slowest rank's launch
+        print(json.dumps({
+            "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
+            "value": tracked * a.steps / t_max, "unit": "tracked features/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": t_max / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8 -> i32 fixed point, f32 sums", "data": "synthetic",
+            "config": {"workload": "%sfixed batch of %d independent %dx%d frame pairs, %d Shi-Tomasi corners each, sharded "
+                                   "round-robin by pair index; maxLevel=%d, 21x21 window, 30 it / eps 0.01" % (
+                                       "BASELINE configs[4]: " if (W, H, NF, NB) == (3840, 2160, 16384, 64) else "",
+                                       NB, W, H, NF, a.max_level),
+                       "pairs_total": NB, "pairs_per_rank": [int(r[2]) for r in recs.tolist()],
+                       "features_in_per_step": NB * NF, "tracked_per_step": tracked,
+                       "pairs_per_s": NB * a.steps / t_max},
+            "roofline": {"bound": "hbm", "kernel": "pyrlk_track_w21", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved": bpf * max(int(r[0]) for r in recs.tolist()) / k3_avg_s / 1e9 if k3_avg_s > 0 else None,
+                         "frac": bpf * max(int(r[0]) for r in recs.tolist()) / k3_avg_s / 1e9 / HBM_PEAK_GBS if k3_avg_s > 0 else None,
+                         "traffic": None, "bytes_model_per_feature": bpf, "avg_launch_ms": k3_avg_s * 1e3,
+                         "note": "per GPU: the slowest rank's launch (all ranks hold the same number of pairs when the "
+                                 "rank count divides the batch)"},
+            "pair_table_crc32": zlib.crc32(table.tobytes()),
+            "per_rank": [{"features_in": r[0], "tracked": r[1], "pairs": r[2], "k3_ms": r[3], "elapsed_s": r[7]}
+                         for r in recs.tolist()]}))
+    ctx.close()
+
+
 def cpu_baseline(frames, pts, max_level, budget_s):
     """The oracle (a port of the OpenCV path the reference calls) timed on the host cores: per
     pair both pyramids, the previous image's Scharr planes and the LK loop, as one
@@ -315,15 +423,30 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+    # Under torchrun (RANK set) the process group is always created, for one rank too: a one-GPU box then runs
+    # the same RCCL initialisation, barrier, all_gather and all_reduce as an 8-GPU node.
+    grouped = world > 1 or "RANK" in os.environ
+    if grouped:
+        # RCCL prints a version banner on the process's stdout when its first communicator comes up; stdout
+        # carries the one JSON line, so file descriptor 1 points at stderr until that has happened
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     if a.workload != "pairs":
-        (run_sequence if a.workload == "sequence" else run_ransac)(a, rank, world, local, dev)
-        if world > 1:
+        {"sequence": run_sequence, "ransac": run_ransac, "batch": run_batch}[a.workload](a, rank, world, local, dev)
+        if grouped:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -400,7 +523,7 @@ def main():
         for c in ctxs:
             c.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
 
     # The GPU idles while the inputs are prepared on the host, and its clocks take some ten launches (about
@@ -566,7 +689,7 @@ def main():
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames[:P + 1], pts[:P], a.max_level, a.cpu_seconds)
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -22,6 +22,12 @@ def shard_round_robin(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
+def _single(world):
+    """No process group (a plain `python bench.py` run): nothing to exchange.  Under torchrun the group
+    exists even for one rank, and the collectives run (so a one-GPU box exercises the RCCL path too)."""
+    return world == 1 and not (dist.is_available() and dist.is_initialized())
+
+
 def _collective_tensor(t):
     """RCCL ("nccl") exchanges device tensors; gloo (CPU tests, rehearsals) wants host tensors."""
     return t.cpu() if dist.get_backend() == "gloo" else t
@@ -29,7 +35,7 @@ def _collective_tensor(t):
 
 def gather_records(rec, world):
     """all_gather of one fixed-size float64 record per rank -> array [world, len(rec)]."""
-    if world == 1:
+    if _single(world):
         return rec.detach().cpu().numpy()[None].copy()
     rec = _collective_tensor(rec)
     out = [torch.zeros_like(rec) for _ in range(world)]
@@ -39,7 +45,7 @@ def gather_records(rec, world):
 
 def gather_trajectories(poses, world):
     """poses: float32 [frames, 16] on this rank -> [world, frames, 16] (same frame count everywhere)."""
-    if world == 1:
+    if _single(world):
         return poses.detach().cpu().numpy()[None].copy()
     poses = _collective_tensor(poses)
     out = [torch.zeros_like(poses) for _ in range(world)]
@@ -47,9 +53,40 @@ def gather_trajectories(poses, world):
     return torch.stack(out).cpu().numpy()
 
 
+PAIR_FIELDS = ("pair", "features_in", "tracked", "status_crc32", "positions_crc32")
+
+
+def gather_pair_records(rows, n_items, world):
+    """Per-item results of a round-robin sharded batch, gathered and put back in item order.
+
+    rows: int64 [k, len(PAIR_FIELDS)] for the k items this rank owns (column 0 = item index).  Every rank
+    contributes a block padded to ceil(n_items / world) rows (item index -1 marks padding), so the one
+    all_gather moves fixed-size blocks.  Returns int64 [n_items, len(PAIR_FIELDS)] ordered by item index,
+    the same array whatever the number of ranks."""
+    width = len(PAIR_FIELDS)
+    per_rank = -(-n_items // world)
+    block = torch.full((per_rank, width), -1, dtype=torch.int64, device=rows.device)
+    block[: rows.shape[0]] = rows
+    if _single(world):
+        blocks = [block.cpu()]
+    else:
+        block = _collective_tensor(block)
+        out = [torch.zeros_like(block) for _ in range(world)]
+        dist.all_gather(out, block)
+        blocks = [b.cpu() for b in out]
+    table = np.full((n_items, width), -1, np.int64)
+    for b in blocks:
+        for row in b.numpy():
+            if row[0] >= 0:
+                assert table[row[0], 0] == -1, "item %d reported twice" % row[0]
+                table[row[0]] = row
+    assert (table[:, 0] == np.arange(n_items)).all(), "an item of the batch was not reported"
+    return table
+
+
 def max_over_ranks(value, device, world):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if world > 1:
+    if not _single(world):
         t = _collective_tensor(t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

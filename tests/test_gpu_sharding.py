@@ -36,3 +36,21 @@ def test_two_rank_gather_equals_single_rank_runs(tmp_path):
         assert o["per_rank"][0]["tracked_points"] == out["per_rank"][r]["tracked_points"]
         assert np.load(one)[0].tobytes() == gathered[r].tobytes(), r
     assert not np.array_equal(gathered[0], gathered[1])    # the ranks really ran different sequences
+
+
+def test_round_robin_batch_equals_single_rank_run(tmp_path):
+    """The fixed-batch workload (BASELINE configs[4] at a reduced frame size): six frame pairs sharded
+    round-robin over two ranks give, pair by pair, the very results of one rank running all six."""
+    common = ["bench.py", "--workload", "batch", "--batch-pairs", "6", "--width", "640", "--height", "360", "--features",
+              "400", "--steps", "2", "--warmup", "1"]
+    two, one = tmp_path / "two.npy", tmp_path / "one.npy"
+    o2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29643"] + common + ["--gpus", "2", "--dump-pairs", str(two)],
+              {"KTLVO_BENCH_REHEARSAL": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    o1 = _run([sys.executable] + common + ["--dump-pairs", str(one)])
+    assert o2["scaling"] == "strong" and o2["n_gpus"] == 2 and o2["config"]["pairs_per_rank"] == [3, 3]
+    assert o1["config"]["pairs_per_rank"] == [6]
+    a, b = np.load(two), np.load(one)
+    assert a.shape == (6, 5) and a.tobytes() == b.tobytes()
+    assert o1["pair_table_crc32"] == o2["pair_table_crc32"]
+    assert (a[:, 2] > 200).all() and len(set(a[:, 4].tolist())) == 6     # every pair tracked, every pair different

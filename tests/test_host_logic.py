@@ -72,6 +72,39 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _pair_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_items = 7                                            # not a multiple of the rank count: one block is padded
+    mine = shard.shard_round_robin(n_items, rank, world)
+    rows = torch.tensor([[p, 100, 90 + p, 1000 + p, 2000 + p] for p in mine], dtype=torch.int64).reshape(-1, 5)
+    table = shard.gather_pair_records(rows, n_items, world)
+    dist.barrier()
+    if rank == 0:
+        q.put(table)
+    dist.destroy_process_group()
+
+
+def test_round_robin_batch_gather_world_size_2_gloo():
+    """The fixed-batch workload's exchange: per-pair rows from two ranks come back in pair order and equal
+    the table a single rank produces for the same batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    table = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rows = torch.tensor([[p, 100, 90 + p, 1000 + p, 2000 + p] for p in range(7)], dtype=torch.int64)
+    single = shard.gather_pair_records(rows, 7, 1)
+    assert table.shape == (7, 5) and np.array_equal(table, single)
+    assert list(table[:, 0]) == list(range(7))
+
+
 def test_gather_world_size_2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -113,7 +146,7 @@ def test_bench_cpu_baseline_leg_runs_on_the_host():
         os.path.abspath(__file__))), "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for name in ("main", "parse", "run_sequence", "run_ransac", "cpu_baseline", "measured_traffic"):
+    for name in ("main", "parse", "run_sequence", "run_ransac", "run_batch", "cpu_baseline", "measured_traffic"):
         assert callable(getattr(bench, name)), name
     a, b = synth.texture_pair(320, 240, 5, 1.5, -0.5, noise=True)
     rng = np.random.default_rng(0)
