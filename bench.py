@@ -60,20 +60,53 @@ def pyramid_bytes(w, h, max_level, win=WIN):
     return total, levels
 
 
-def measured_traffic(kernel, waves_per_launch):
+def source_sha1(rel):
+    import hashlib
+    try:
+        return hashlib.sha1(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def measured_traffic(kernel, waves_per_launch, source="slam_amd/csrc/pyrlk.hip"):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/r*_pmc_summary.json, written by profiles/summarize_pmc.py from separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE
-    doubling applied).  None if no summary matches this launch shape."""
+    doubling applied).  Counters describe the kernel they were collected on: a summary that records the
+    SHA-1 of the kernel's source file is only used while that file is unchanged.  None if no summary
+    matches this launch shape and source."""
     import glob
+    sha = source_sha1(source)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
-            e = json.load(open(path)).get(kernel)
+            doc = json.load(open(path))
         except (OSError, ValueError):
             continue
+        e = doc.get(kernel)
+        want = (doc.get("_source_sha1") or {}).get(source)
+        if want is not None and want != sha:
+            continue   # collected on another version of the kernel
         if e and "hbm_bytes_per_launch" in e and int(e.get("SQ_WAVES", -1)) == int(waves_per_launch):
             return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), e
     return None, None, None
+
+
+def issue_ceiling():
+    """Measured issue cost, in shader cycles per wave-instruction per SIMD, of the LK step's instruction mix at
+    8 waves per SIMD (tools/probe/issue_rate.hip, result committed under profiles/)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_rate.json")), reverse=True):
+        try:
+            rows = json.load(open(path))["rows"]
+        except (OSError, ValueError, KeyError):
+            continue
+        pick = {r["kind"]: r for r in rows if r.get("blocks_per_cu") == 8}
+        if "lk_step_mix" in pick:
+            return {"cycles_per_inst_lk_mix": pick["lk_step_mix"]["cyc_per_inst_simd"],
+                    "cycles_per_inst_v_fma_f32": pick.get("v_fma_f32", {}).get("cyc_per_inst_simd"),
+                    "cycles_per_inst_v_dot2_i32_i16": pick.get("v_dot2_i32_i16", {}).get("cyc_per_inst_simd"),
+                    "clock_ghz_in_probe": pick["lk_step_mix"]["clock_ghz"], "source": os.path.relpath(path, ROOT)}
+    return None
 
 
 def parse():
@@ -93,6 +126,10 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=1,
                     help="contexts (each with its own stream and slots) the steps alternate between, so one "
                          "step's pyramid build overlaps the previous step's LK tail")
+    ap.add_argument("--skip-stream", action="store_true", help="leave out the host-fed (PCIe-inclusive) measurement")
+    ap.add_argument("--soak", type=float, default=0.0,
+                    help="seconds of extra back-to-back steps after the measurement (keeps the GPU busy long enough for "
+                         "an external sampler such as rocm-smi to see it); reported separately")
     ap.add_argument("--skip-secondary", action="store_true",
                     help="leave out the maxLevel-3 run (profiling passes: one launch shape per kernel)")
     ap.add_argument("--time-kernels", choices=["lk", "all"], default="lk",
@@ -564,6 +601,64 @@ def main():
         c.profile_enable(False)
 
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
+
+    # ---- the same step fed from host memory every time (frame-pair STREAM, never the headline) ------------
+    # One batched DMA per step (ktlvo_upload_images from a pinned buffer) on three contexts with a stream each,
+    # steps taking them in turn: a step's upload (DMA engine) and pyramid build run under the LK launches of
+    # the two steps before it.  (With two contexts a step's upload can only start once the step before last
+    # has finished, which leaves its pyramid build uncovered.)
+    streamed = None
+    if rank == 0 and not a.skip_stream:
+        host = torch.from_numpy(np.stack(frames)).pin_memory()
+        NS = 3
+        two = list(ctxs[:NS]) + [K.Context(cfg, device=local) for _ in range(NS - min(NS, len(ctxs)))]
+        so = list(outs[:NS]) + [tuple(torch.zeros_like(t) for t in outs[0]) for _ in range(NS - min(NS, len(outs)))]
+
+        def stream_step(k, overlap):
+            c, (o_next, o_status, o_err) = two[k % NS if overlap else 0], so[k % NS if overlap else 0]
+            c.upload_images(slots, host.numpy())
+            c.build_pyramids(slots)
+            c.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, o_next.data_ptr(), o_status.data_ptr(),
+                              o_err.data_ptr(), lk)
+
+        def timed_stream(overlap, n):
+            for k in range(4):
+                stream_step(k, overlap)
+            for c in two:
+                c.sync()
+            t = time.perf_counter()
+            for k in range(n):
+                stream_step(k, overlap)
+            for c in two:
+                c.sync()
+            return (time.perf_counter() - t) / n
+
+        def timed_dma(n):
+            two[0].sync()
+            t = time.perf_counter()
+            for _ in range(n):
+                two[0].upload_images(slots, host.numpy())
+            two[0].sync()
+            return (time.perf_counter() - t) / n
+
+        n_s = max(6, a.steps)
+        t_dma = timed_dma(n_s)
+        t_serial = timed_stream(False, n_s)
+        t_overlap = timed_stream(True, n_s)
+        assert all(int(o[1].sum().item()) == tracked for o in so)
+        streamed = {"ms_per_step": {"upload_alone": t_dma * 1e3, "upload_then_compute_one_stream": t_serial * 1e3,
+                                    "three_streams_overlapped": t_overlap * 1e3, "compute_alone": None},
+                    "host_link_GBps": NI * W * H / t_dma / 1e9,
+                    "value_one_stream": tracked / t_serial, "value_overlapped": tracked / t_overlap,
+                    "note": "rank 0: all %d frames of a step (%.1f MB) uploaded from pinned host memory every step in ONE "
+                            "DMA + one ingest launch (ktlvo_upload_images); overlapped = three contexts, a stream each, "
+                            "steps taking them in turn" % (NI, NI * W * H / 1e6)}
+        for c in two[len(ctxs):]:
+            c.close()
+        two[0].upload_images(slots, host.numpy())      # leave context 0 as the main run had it
+        two[0].build_pyramids(slots)
+        two[0].sync()
+        del host
     # the same step with maxLevel 3 (4 pyramid images), in case "4-level" is read that way
     ml3 = None
     if world == 1 and a.max_level == 4 and not a.skip_secondary:
@@ -585,6 +680,18 @@ def main():
         ml3 = {"value": tr3 * n3 / t3, "unit": "tracked features/s", "steps": n3, "tracked_per_step": tr3}
         ctx.build_pyramids(slots)   # leave the slots as the main run built them
         fence()
+    soak = None
+    if a.soak > 0:
+        fence()
+        t_s, n_s = time.perf_counter(), 0
+        while time.perf_counter() - t_s < a.soak:
+            for _ in range(20):
+                step()
+            n_s += 20
+            for c in ctxs:
+                c.sync()
+        t_s = time.perf_counter() - t_s
+        soak = {"seconds": t_s, "steps": n_s, "value_this_rank": tracked * n_s / t_s}
     rec = torch.tensor([float(NP * NF), float(tracked), float(NP), k3_ms, float(k3_n), k1_ms, float(k1_n), elapsed],
                        dtype=torch.float64, device=dev)
     t_max = shard.max_over_ranks(elapsed, dev, world)
@@ -602,20 +709,25 @@ def main():
             lv_bytes += w_ * h_
             w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
         traffic, traffic_src, pmc = measured_traffic("pyrlk_track_w21", feats_per_launch)
-        # what the kernel is really limited by: vector-ALU issue.  A 64-lane VALU instruction holds a
-        # 16-lane SIMD for 4 cycles; 256 CUs x 4 SIMDs; 2.4 GHz is the part's peak engine clock.
-        # Instruction count from the same PMC summary as `traffic`.  A fraction at or slightly above 1
-        # means that every issue slot is taken (some counted instructions, v_readlane for one, need
-        # fewer than 4 cycles).
+        # What the kernel is really limited by: vector-ALU issue.  The ceiling is MEASURED (tools/probe/issue_rate.hip):
+        # on gfx950 a SIMD issues v_fma_f32 / v_add_f32 every 2.2 cycles but integer, permute, dot2-i16, DPP,
+        # convert and packed-f32 instructions every 4.2; the LK step's own mix costs 3.9 cycles per
+        # wave-instruction.  Achieved = 1024 SIMDs x shader clock x kernel time / SQ_INSTS_VALU, with the
+        # instruction count and the kernel's clock (GRBM_GUI_ACTIVE / 8 / duration under the counters) from
+        # the same PMC summary as `traffic`.
         valu = None
+        ceil = issue_ceiling()
         if pmc and pmc.get("SQ_INSTS_VALU") and k3_avg_s > 0:
-            per_simd_ns = pmc["SQ_INSTS_VALU"] / (1024 * k3_avg_s * 1e9)
+            clock = pmc.get("clock_ghz") or (ceil or {}).get("clock_ghz_in_probe") or 2.4
+            cyc_per_inst = 1024.0 * clock * 1e9 * k3_avg_s / pmc["SQ_INSTS_VALU"]
             valu = {"insts_per_feature": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
                     "vmem_insts_per_feature": pmc.get("SQ_INSTS_VMEM", 0.0) / pmc["SQ_WAVES"],
-                    "wave_insts_per_simd_per_ns": per_simd_ns,
-                    "issue_busy_frac": per_simd_ns * 4.0 / 2.4,
-                    "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time); "
-                            "counters from " + traffic_src}
+                    "shader_clock_ghz": clock, "clock_source": "GRBM_GUI_ACTIVE" if pmc.get("clock_ghz") else "probe",
+                    "cycles_per_wave_inst_per_simd": cyc_per_inst,
+                    "ceiling": ceil,
+                    "issue_frac": (ceil["cycles_per_inst_lk_mix"] / cyc_per_inst) if ceil else None,
+                    "note": "achieved cycles per wave-instruction per SIMD against the measured issue cost of the "
+                            "kernel's instruction mix; counters from " + traffic_src}
         out = {
             "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
             "value": value,
@@ -648,7 +760,11 @@ def main():
                 "pairs_per_s": agg["pairs_per_s"],
             },
             "roofline": {
+                # the contract's figure: algorithmic bytes of the gather model over the launch time against HBM
+                # peak.  The kernel itself is bound by vector-instruction issue (`limiter`, `valu`), its real
+                # HBM traffic is `hbm_measured_GBps`.
                 "bound": "hbm",
+                "limiter": "valu_issue",
                 "kernel": "pyrlk_track_w21",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -657,6 +773,7 @@ def main():
                 "frac_of_measured_copy_ceiling": achieved / HBM_COPY_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "hbm_measured_GBps": (traffic / k3_avg_s / 1e9) if (traffic and k3_avg_s > 0) else None,
                 "bytes_model_per_feature": bpf,
                 # compulsory-unique traffic of one pair: both pyramids read once + point I/O
                 "bytes_rocprof_per_feature": (traffic / feats_per_launch) if traffic else None,
@@ -676,7 +793,8 @@ def main():
                                   "achieved_GBps": 5 * lv_bytes * NI / max(k2_ms / max(k2_n, 1) * 1e-3, 1e-12) / 1e9},
                 "pyrlk_track_w21": {"avg_ms_per_step": k3_ms / max(k3_n, 1)},
             },
-            "h2d_inclusive": {"value": total_tracked / world / (t_max / a.steps + t_h2d),
+            "h2d_inclusive": {"streamed": streamed,
+                              "value": total_tracked / world / (t_max / a.steps + t_h2d),
                               "value_pinned_source": total_tracked / world / (t_max / a.steps + t_h2d_pinned),
                               "upload_ms": {"pageable_source": t_h2d * 1e3, "pinned_source": t_h2d_pinned * 1e3},
                               "note": "rank-0 rate if the %d frames of a step were uploaded from host memory "
@@ -684,6 +802,10 @@ def main():
             "per_rank": [{"features_in": r[0], "tracked": r[1], "k3_ms": r[3], "k1_ms": r[5], "elapsed_s": r[7]}
                          for r in recs.tolist()],
         }
+        if streamed is not None:
+            streamed["ms_per_step"]["compute_alone"] = t_max / a.steps * 1e3
+        if soak is not None:
+            out["soak"] = soak
         if ml3 is not None:
             out["max_level_3"] = ml3
         if world == 1 and a.cpu_seconds > 0:

@@ -112,6 +112,13 @@ const char *ktlvo_last_error(const ktlvo_ctx *ctx); /* text of the last HIP fail
  * is read by DMA after the call returns: leave it unchanged until a call that waits for the device
  * (ktlvo_sync, or any host-pointer call that returns results, ktlvo_track_stereo_frame included). */
 int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride);
+/* The same for n frames at once (n <= 256), frame i starting image_stride bytes after frame i - 1 and going
+ * into slots[i]: one DMA and one launch for the whole batch instead of one each per frame, which is what
+ * a frame-pair stream needs to use the host link at its rate (the reference receives its frames one
+ * ROS message at a time, featureTracking.cpp:339-347; a replay harness or a multi-camera rig has them in
+ * bulk).  Source memory as for ktlvo_upload_image. */
+int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, const uint8_t *imgs, int w, int h,
+                        int stride, size_t image_stride);
 /* Same from a device buffer (frame already resident in HBM). */
 int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride);
 /* cv::buildOpticalFlowPyramid as called inside calcOpticalFlowPyrLK (featureTracking.cpp:205):

@@ -9,9 +9,13 @@ For narrower gathers the factor is uncalibrated: the doubled value is an upper e
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -22,6 +26,10 @@ def main():
             # "void ktlvo::pyrlk_track_w21<4>(ktlvo::LkArgs)" -> "pyrlk_track_w21": instantiations of one kernel pool
             k = re.sub(r"<[^<>]*>", "", r["Kernel_Name"].split("(")[0]).replace("ktlvo::", "").replace("void ", "").strip()
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                ns = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                if ns > 0:   # the counter is summed over the 8 XCDs: shader clock = cycles / 8 / duration
+                    agg[k]["clock_ghz"].append(float(r["Counter_Value"]) / 8.0 / ns)
     res = {}
     for k, d in agg.items():
         if k.startswith(("at::", "void at::", "__amd")):
@@ -36,8 +44,16 @@ def main():
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
             e["vmem_insts_per_wave"] = e.get("SQ_INSTS_VMEM", 0.0) / e["SQ_WAVES"]
         res[k] = e
+    # the counters describe these versions of the kernel sources (bench.py ignores a summary whose hashes are stale)
+    res["_source_sha1"] = {}
+    for rel in ("slam_amd/csrc/pyrlk.hip", "slam_amd/csrc/pyramid.hip", "slam_amd/csrc/corners.hip"):
+        try:
+            res["_source_sha1"][rel] = hashlib.sha1(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+        except OSError:
+            pass
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
-    print(json.dumps({k: {kk: vv for kk, vv in v.items() if "per_" in kk} for k, v in res.items()}, indent=1))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if "per_" in kk or kk == "clock_ghz"} for k, v in res.items()
+                      if not k.startswith("_")}, indent=1))
 
 
 if __name__ == "__main__":

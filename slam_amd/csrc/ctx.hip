@@ -190,6 +190,9 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
         if (ctx->stage.d_buf[i]) (void)hipFree(ctx->stage.d_buf[i]);
         if (ctx->stage.done[i]) (void)hipEventDestroy(ctx->stage.done[i]);
     }
+    if (ctx->stage.d_batch) (void)hipFree(ctx->stage.d_batch);
+    if (ctx->stage.h_batch) (void)hipHostFree(ctx->stage.h_batch);
+    if (ctx->stage.batch_done) (void)hipEventDestroy(ctx->stage.batch_done);
     for (int i = 0; i < 4; i++) if (ctx->d_pts[i]) (void)hipFree(ctx->d_pts[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_err) (void)hipFree(ctx->d_err);

@@ -54,6 +54,11 @@ struct StageRing {
     hipEvent_t done[N] = {nullptr, nullptr, nullptr, nullptr};
     bool used[N] = {false, false, false, false};
     int next = 0;
+    // ktlvo_upload_images: one device buffer (and, for pageable sources, one pinned buffer) for a whole batch
+    uint8_t *d_batch = nullptr, *h_batch = nullptr;
+    size_t batch_bytes = 0;
+    hipEvent_t batch_done = nullptr;
+    bool batch_used = false;
 };
 
 struct TrackerState; // tracker.hip

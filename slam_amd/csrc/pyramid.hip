@@ -16,14 +16,33 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-// Ingest: copies a w x h image (row stride `stride`) into level 0 of a slot and fills the
-// reflect-101 frame in the same pass: one thread per byte of the padded plane.
+// Ingest: copies a w x h image (row stride `stride`) into level 0 of a slot and fills the reflect-101 frame
+// in the same pass.  A thread makes four consecutive bytes of the padded plane (one aligned word store; the
+// plane's origin, pitch and PAD are multiples of four); away from the left and right edges its four source
+// bytes are consecutive too.
+__device__ __forceinline__ void ingest_quad(const LevelDesc &L, const uint8_t *src, int stride, int x, int y) {
+    if (x >= L.w + PAD || y >= L.h + PAD) return;
+    const uint8_t *row = src + (size_t)reflect101(y, L.h) * stride;
+    uint32_t v;
+    if (x >= 0 && x + 3 < L.w) {
+        v = (uint32_t)row[x] | ((uint32_t)row[x + 1] << 8) | ((uint32_t)row[x + 2] << 16) | ((uint32_t)row[x + 3] << 24);
+    } else {
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
+    }
+    *(uint32_t *)(L.origin + (ptrdiff_t)y * L.pitch + x) = v;
+}
 __global__ __launch_bounds__(256) void ingest_pad_u8(const SlotDesc *slots, int slot, const uint8_t *src, int stride) {
     const LevelDesc L = slots[slot].lv[0];
-    const int x = (int)(blockIdx.x * 64 + (threadIdx.x & 63)) - PAD;
-    const int y = (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PAD;
-    if (x >= L.w + PAD || y >= L.h + PAD) return;
-    L.origin[(ptrdiff_t)y * L.pitch + x] = src[(size_t)reflect101(y, L.h) * stride + reflect101(x, L.w)];
+    ingest_quad(L, src, stride, (int)(blockIdx.x * 256 + (threadIdx.x & 63) * 4) - PAD, (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PAD);
+}
+// The same for a batch: image z of a contiguous device buffer (image_stride bytes apart) goes into slot list.s[z].
+__global__ __launch_bounds__(256) void ingest_pad_batch_u8(const SlotDesc *slots, SlotList list, const uint8_t *src,
+                                                           size_t image_stride, int stride) {
+    const LevelDesc L = slots[list.s[blockIdx.z]].lv[0];
+    ingest_quad(L, src + blockIdx.z * image_stride, stride, (int)(blockIdx.x * 256 + (threadIdx.x & 63) * 4) - PAD,
+                (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PAD);
 }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
 }
 
 static int launch_ingest(ktlvo_ctx *ctx, int slot, const uint8_t *d_src, int stride) {
-    dim3 grid((ctx->cfg.width + 2 * PAD + 63) / 64, (ctx->cfg.height + 2 * PAD + 3) / 4, 1);
+    dim3 grid((ctx->cfg.width + 2 * PAD + 255) / 256, (ctx->cfg.height + 2 * PAD + 3) / 4, 1);
     hipLaunchKernelGGL(ingest_pad_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, d_src, stride);
     KTLVO_HIP(ctx, hipGetLastError());
     ctx->built[slot] = 0;
@@ -256,6 +275,53 @@ extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, 
     if (rc != KTLVO_OK) return rc;
     KTLVO_HIP(ctx, hipEventRecord(r.done[k], ctx->stream));
     r.used[k] = true;
+    return KTLVO_OK;
+}
+
+// A whole batch of frames in one DMA and one ingest launch.  A per-frame upload moves 466 KB per DMA for a
+// KITTI-sized frame, which the host link serves at well under half its rate; one transfer of the whole batch
+// runs at the link's rate, and issued on a context of its own it overlaps another context's kernels.
+extern "C" int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, const uint8_t *imgs, int w, int h, int stride,
+                                   size_t image_stride) {
+    if (!ctx || n < 0 || (n > 0 && (!slots || !imgs))) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (n == 0) return KTLVO_OK;
+    if (w != ctx->cfg.width || h != ctx->cfg.height || stride < w || image_stride < (size_t)stride * (h - 1) + w)
+        return KTLVO_ERR_INVALID;
+    if (n > MAX_BATCH) return KTLVO_ERR_CAPACITY;
+    for (int i = 0; i < n; i++)
+        if (!slot_ok(ctx, slots[i])) return KTLVO_ERR_INVALID;
+    const size_t bytes = image_stride * (size_t)(n - 1) + (size_t)stride * (h - 1) + w;
+    StageRing &r = ctx->stage;
+    if (bytes > r.batch_bytes) {
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (r.d_batch) KTLVO_HIP(ctx, hipFree(r.d_batch));
+        if (r.h_batch) KTLVO_HIP(ctx, hipHostFree(r.h_batch));
+        r.d_batch = r.h_batch = nullptr;
+        r.batch_bytes = 0;
+        KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch, bytes));
+        r.batch_bytes = bytes;
+    }
+    if (!r.batch_done) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.batch_done, hipEventDisableTiming));
+    if (r.batch_used) KTLVO_HIP(ctx, hipEventSynchronize(r.batch_done)); // the previous batch has left the staging buffers
+    hipPointerAttribute_t attr;
+    const uint8_t *src = imgs;
+    if (!(hipPointerGetAttributes(&attr, imgs) == hipSuccess && attr.type == hipMemoryTypeHost)) {
+        (void)hipGetLastError();
+        if (!r.h_batch) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_batch, r.batch_bytes, hipHostMallocDefault));
+        memcpy(r.h_batch, imgs, bytes); // pageable source: staged, so the call returns with the caller's buffer free
+        src = r.h_batch;
+    }
+    KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SlotList list;
+    list.n = n;
+    for (int i = 0; i < n; i++) list.s[i] = slots[i];
+    dim3 grid((w + 2 * PAD + 255) / 256, (h + 2 * PAD + 3) / 4, n);
+    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, r.d_batch, image_stride, stride);
+    KTLVO_HIP(ctx, hipGetLastError());
+    KTLVO_HIP(ctx, hipEventRecord(r.batch_done, ctx->stream));
+    r.batch_used = true;
+    for (int i = 0; i < n; i++) { ctx->built[slots[i]] = 0; ctx->deriv_ok[slots[i]] = 0; }
     return KTLVO_OK;
 }
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "ktlvo_strerror": (C.c_char_p, [_i]),
     "ktlvo_last_error": (C.c_char_p, [_vp]),
     "ktlvo_upload_image": (_i, [_vp, _i, _vp, _i, _i, _i]),
+    "ktlvo_upload_images": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, C.c_size_t]),
     "ktlvo_set_image_dev": (_i, [_vp, _i, _vp, _i, _i, _i]),
     "ktlvo_build_pyramid": (_i, [_vp, _i, _i, _i]),
     "ktlvo_build_pyramids": (_i, [_vp, _ip, _i, _i, _i]),
@@ -255,6 +256,14 @@ class Context:
             img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         self._chk(lib.ktlvo_upload_image(self._h, slot, _ptr(img), w, h, img.strides[0]), "ktlvo_upload_image")
+
+    def upload_images(self, slots, imgs):
+        """imgs: uint8 (n, h, w) contiguous (pageable or pinned); frame i goes into slots[i]: one DMA, one launch."""
+        imgs = np.asarray(imgs)
+        assert imgs.dtype == np.uint8 and imgs.ndim == 3 and imgs.flags["C_CONTIGUOUS"] and len(slots) == imgs.shape[0]
+        n, h, w = imgs.shape
+        arr = (C.c_int * max(n, 1))(*slots)
+        self._chk(lib.ktlvo_upload_images(self._h, arr, n, _ptr(imgs), w, h, w, w * h), "ktlvo_upload_images")
 
     def set_image_dev(self, slot, dptr, w, h, stride):
         self._chk(lib.ktlvo_set_image_dev(self._h, slot, dptr, w, h, stride), "ktlvo_set_image_dev")

@@ -473,6 +473,33 @@ def test_get_optical_flow_matches_composition(make_ctx, oracle):
     assert 100 < len(idx) < 1500
 
 
+def test_batched_upload_equals_per_frame_upload(make_ctx):
+    """ktlvo_upload_images (one DMA, one ingest launch) fills the slots exactly as n ktlvo_upload_image calls do,
+    from pageable and from pinned memory, into slots given in any order."""
+    import torch
+    W, H, n = 322, 203, 5
+    rng = np.random.default_rng(8)
+    imgs = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    a, b, c = (make_ctx(width=W, height=H, num_slots=n) for _ in range(3))
+    order = [3, 0, 4, 1, 2]
+    for i, s in enumerate(order):
+        a.upload_image(s, imgs[i])
+    b.upload_images(order, imgs)
+    pinned = torch.from_numpy(imgs).pin_memory()
+    c.upload_images(order, pinned.numpy())
+    c.sync()
+    pinned.fill_(7)                      # after the sync the pinned source is free again
+    for ctx in (a, b, c):
+        ctx.build_pyramids(list(range(n)))
+    for s in range(n):
+        for l in range(a.pyramid_levels(s) + 1):
+            ref = a.download_level(s, l)
+            assert np.array_equal(b.download_level(s, l), ref) and np.array_equal(c.download_level(s, l), ref)
+    pts = np.stack([rng.uniform(0, W, 200), rng.uniform(0, H, 200)], 1).astype(np.float32)
+    ra, rb = a.pyrlk(0, 1, pts), b.pyrlk(0, 1, pts)        # the frames (reflect-101 borders) are the same too
+    assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+
+
 # ---------------------------------------------------------------- RANSAC ----------------------
 def test_ransac_score_counts_exact(make_ctx, oracle):
     g = np.load(os.path.join(GOLD, "ransac_400.npz"))
