@@ -127,6 +127,7 @@ struct ProfScope {
 };
 
 int corner_noalloc_init(ktlvo_ctx *ctx); // corners.hip
+int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const uint8_t *b, int w, int h); // pyramid.hip
 int ensure_misc(ktlvo_ctx *ctx, size_t bytes);
 int ensure_pin(ktlvo_ctx *ctx, size_t bytes);
 inline bool slot_ok(const ktlvo_ctx *ctx, int s) { return s >= 0 && s < ctx->cfg.num_slots; }

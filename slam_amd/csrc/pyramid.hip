@@ -325,6 +325,50 @@ extern "C" int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, cons
     return KTLVO_OK;
 }
 
+namespace ktlvo {
+// Two frames (a stereo pair) into two slots with one ingest launch, and for pageable sources one DMA: the
+// per-frame path's set-up cost is a handful of runtime calls, and this halves them.
+int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const uint8_t *b, int w, int h) {
+    const size_t bytes = (size_t)w * h, img_stride = (bytes + 255) & ~(size_t)255;
+    StageRing &r = ctx->stage;
+    if (2 * img_stride > r.batch_bytes) {
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (r.d_batch) KTLVO_HIP(ctx, hipFree(r.d_batch));
+        if (r.h_batch) KTLVO_HIP(ctx, hipHostFree(r.h_batch));
+        r.d_batch = r.h_batch = nullptr;
+        r.batch_bytes = 0;
+        KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch, 2 * img_stride));
+        r.batch_bytes = 2 * img_stride;
+    }
+    if (!r.batch_done) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.batch_done, hipEventDisableTiming));
+    if (r.batch_used) KTLVO_HIP(ctx, hipEventSynchronize(r.batch_done));
+    hipPointerAttribute_t attr;
+    const bool pinned = hipPointerGetAttributes(&attr, a) == hipSuccess && attr.type == hipMemoryTypeHost &&
+                        hipPointerGetAttributes(&attr, b) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (pinned) { // read by DMA where they lie
+        KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch + img_stride, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        (void)hipGetLastError();
+        if (!r.h_batch) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_batch, r.batch_bytes, hipHostMallocDefault));
+        memcpy(r.h_batch, a, bytes);
+        memcpy(r.h_batch + img_stride, b, bytes);
+        KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch, r.h_batch, img_stride + bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SlotList list;
+    list.n = 2;
+    list.s[0] = slot_a; list.s[1] = slot_b;
+    dim3 grid((w + 2 * PAD + 255) / 256, (h + 2 * PAD + 3) / 4, 2);
+    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, r.d_batch, img_stride, w);
+    KTLVO_HIP(ctx, hipGetLastError());
+    KTLVO_HIP(ctx, hipEventRecord(r.batch_done, ctx->stream));
+    r.batch_used = true;
+    ctx->built[slot_a] = ctx->built[slot_b] = 0;
+    ctx->deriv_ok[slot_a] = ctx->deriv_ok[slot_b] = 0;
+    return KTLVO_OK;
+}
+} // namespace ktlvo
+
 extern "C" int ktlvo_set_image_dev(ktlvo_ctx *ctx, int slot, const uint8_t *d_img, int w, int h, int stride) {
     if (!ctx || !d_img || !slot_ok(ctx, slot)) return KTLVO_ERR_INVALID;
     KTLVO_BIND(ctx);

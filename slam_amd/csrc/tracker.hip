@@ -76,8 +76,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     const int W = c.width, H = c.height;
 
     if (!t->inited) { // :349-356
-        if ((rc = ktlvo_upload_image(ctx, t->sCurL, left, W, H, W)) != KTLVO_OK) return rc;
-        if ((rc = ktlvo_upload_image(ctx, t->sCurR, right, W, H, W)) != KTLVO_OK) return rc;
+        if ((rc = upload_pair(ctx, t->sCurL, t->sCurR, left, right, W, H)) != KTLVO_OK) return rc;
         const int s[2] = {t->sCurL, t->sCurR};
         if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
         // the caller may reuse (pinned) frame buffers as soon as this call returns
@@ -96,8 +95,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         t->sLastL = sLL; t->sLastR = sLR; t->sCurL = sCL; t->sCurR = sCR;
         t->imagePointsCur.swap(newPointsCur);
     };
-    if ((rc = ktlvo_upload_image(ctx, sCL, left, W, H, W)) != KTLVO_OK) return rc;
-    if ((rc = ktlvo_upload_image(ctx, sCR, right, W, H, W)) != KTLVO_OK) return rc;
+    if ((rc = upload_pair(ctx, sCL, sCR, left, right, W, H)) != KTLVO_OK) return rc;
     {
         const int s[2] = {sCL, sCR};
         if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
