@@ -73,9 +73,19 @@ __global__ void corner_setup(RoiTable t, int n_roi, RoiDev *rois, unsigned *roi_
 
 __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, int slot, const RoiDev *rois, float s1,
                                                          float s2, int harris, double k, float *resp_out,
-                                                         unsigned *roi_max, unsigned long long *cand, int *cand_cnt) {
-    const RoiDev R = rois[blockIdx.z];
-    const int tx0 = blockIdx.x * CT, ty0 = blockIdx.y * CT;
+                                                         unsigned *roi_max, unsigned long long *cand, int *cand_cnt,
+                                                         int3 tiles) {
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Consecutive ids therefore take
+    // tiles that lie an eighth of the launch apart, and the workgroups of one XCD walk a contiguous run of
+    // tiles in raster order: neighbouring tiles, which share image lines (32-pixel tiles, 128-byte lines) and
+    // halo rows, then meet in one L2 instead of fetching those lines from memory once per XCD.
+    const int tiles_x = tiles.x, tiles_per_roi = tiles.x * tiles.y, n_tiles = tiles_per_roi * tiles.z;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int roi_id = tile / tiles_per_roi, tr = tile - roi_id * tiles_per_roi;
+    const RoiDev R = rois[roi_id];
+    const int tx0 = (tr % tiles_x) * CT, ty0 = (tr / tiles_x) * CT;
     if (tx0 >= R.w || ty0 >= R.h) return;
     const LevelDesc L = slots[slot].lv[0];
     __shared__ uint8_t img[CI][CI + 2];
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
         rsp[py][px] = r;
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(&roi_max[blockIdx.z], f2ord(vmax));
+    if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(&roi_max[roi_id], f2ord(vmax));
     if (!cand) return;
     __syncthreads();
 
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
         for (int w = 0; w < 4; w++)
 #pragma unroll
             for (int q = 0; q < 4; q++) { const int c = wave_cnt[w][q]; wave_cnt[w][q] = total; total += c; }
-        block_base = total ? atomicAdd(&cand_cnt[blockIdx.z], total) : 0;
+        block_base = total ? atomicAdd(&cand_cnt[roi_id], total) : 0;
     }
     __syncthreads();
 #pragma unroll
@@ -356,18 +366,19 @@ __global__ __launch_bounds__(256) void cand_filter(const unsigned long long *can
 constexpr int BL = 4096;
 __device__ __forceinline__ void bitonic_lds_steps(unsigned long long *s, int n_local, size_t gbase, size_t k, int j_from) {
     for (int j = j_from; j > 0; j >>= 1) {
-        for (int i = threadIdx.x; i < n_local; i += blockDim.x) {
-            const int p = i ^ j;
-            if (p > i) {
-                const unsigned long long x = s[i], y = s[p];
-                const bool desc = ((gbase + i) & k) == 0;
-                if (desc ? x < y : x > y) { s[i] = y; s[p] = x; }
-            }
+        // thread t owns the pair (i, i | j), i = t with a zero bit inserted at position log2(j): every thread
+        // has work in every step, and its pairs' loads go out together
+#pragma unroll 4
+        for (int t = threadIdx.x; t < (n_local >> 1); t += blockDim.x) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+            const unsigned long long x = s[i], y = s[p];
+            const bool desc = ((gbase + i) & k) == 0;
+            if (desc ? x < y : x > y) { s[i] = y; s[p] = x; }
         }
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(512) void bitonic_local_sort(unsigned long long *keys, int np2) {
+__global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *keys, int np2) {
     __shared__ unsigned long long s[BL];
     const int n_local = np2 < BL ? np2 : BL;
     const size_t gbase = (size_t)blockIdx.x * BL;
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(512) void bitonic_local_sort(unsigned long long *ke
     for (int k = 2; k <= n_local; k <<= 1) bitonic_lds_steps(s, n_local, gbase, (size_t)k, k >> 1);
     for (int i = threadIdx.x; i < n_local; i += blockDim.x) keys[gbase + i] = s[i];
 }
-__global__ __launch_bounds__(512) void bitonic_local_merge(unsigned long long *keys, unsigned k) {
+__global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *keys, unsigned k) {
     __shared__ unsigned long long s[BL];
     const size_t gbase = (size_t)blockIdx.x * BL;
     for (int i = threadIdx.x; i < BL; i += blockDim.x) s[i] = keys[gbase + i];
@@ -440,9 +451,12 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     };
     if (tid == 0) s_total = 0;
     __syncthreads();
+    unsigned long long next_key = tid < n ? a.keys[tid] : 0ull; // a chunk's keys are fetched one chunk ahead
     for (int base = 0; base < n; base += CH) {
         const int total0 = s_total;
         if (total0 >= a.limit) break;
+        const unsigned long long my_key = next_key;
+        if (base + CH + tid < n) next_key = a.keys[base + CH + tid];
         // what the previous chunk stored must be read from L2, not from this CU's L1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         for (int q = tid; q < HT; q += CH) ht_key[q] = 0u;
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         int x = 0, y = 0, xc = 0, yc = 0;
         bool surv = false;
         if (i < n) {
-            key = a.keys[i];
+            key = my_key;
             const unsigned idx = (unsigned)key;
             y = idx / a.w; x = idx - y * a.w;
             xc = x / a.cell; yc = y / a.cell;
@@ -514,8 +528,8 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                 }
             state = any ? 0 : 1;
         }
-        // (3) rounds
-        for (;;) {
+        // (3) rounds (none when no survivor of the chunk has a predecessor within reach, the usual case)
+        while (__syncthreads_or(state == 0)) {
             const unsigned long long va = __ballot(state == 1), vr = __ballot(state == 2);
             if (lane == 0) {
                 accm[2 * wave] = (unsigned)va; accm[2 * wave + 1] = (unsigned)(va >> 32);
@@ -532,7 +546,6 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                 if (hit) state = 2;
                 else if (!pending) state = 1;
             }
-            if (!__syncthreads_or(state == 0)) break;
         }
         // (4) accepted survivors, in rank order
         const unsigned long long va = __ballot(state == 1);
@@ -650,9 +663,10 @@ static int run_candidates(ktlvo_ctx *ctx, int slot, int n_roi, int maxw, int max
                           const CornerScratch &s, float *d_resp_out, bool want_candidates) {
     const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0); // cornerEigenValsVecs: 2^(ksize-1) * blockSize * 255
     const float s1 = (float)(1.0 * scale), s2 = (float)(2.0 * scale);
-    dim3 grid((maxw + CT - 1) / CT, (maxh + CT - 1) / CT, n_roi);
-    hipLaunchKernelGGL(corner_candidates, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois, s1, s2, use_harris, k,
-                       d_resp_out, s.d_max, want_candidates ? s.d_cand : nullptr, s.d_cnt);
+    const int3 tiles = {(maxw + CT - 1) / CT, (maxh + CT - 1) / CT, n_roi};
+    const int n_tiles = tiles.x * tiles.y * tiles.z;
+    hipLaunchKernelGGL(corner_candidates, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois,
+                       s1, s2, use_harris, k, d_resp_out, s.d_max, want_candidates ? s.d_cand : nullptr, s.d_cnt, tiles);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }
@@ -718,12 +732,12 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
                        p->quality, d_keys, d_n);
     KTLVO_HIP(ctx, hipGetLastError());
     // How many passed is only known on the device; the sort is sized for the candidate count, which bounds it.
-    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL)), dim3(512), 0, ctx->stream, d_keys, (int)np2);
+    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL)), dim3(1024), 0, ctx->stream, d_keys, (int)np2);
     for (size_t k = 2 * (size_t)BL; k <= np2; k <<= 1) {
         for (size_t j = k >> 1; j >= (size_t)BL; j >>= 1)
             hipLaunchKernelGGL(bitonic_global_step, dim3((unsigned)(np2 / 512)), dim3(256), 0, ctx->stream, d_keys, (unsigned)j,
                                (unsigned)k);
-        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL)), dim3(512), 0, ctx->stream, d_keys, (unsigned)k);
+        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL)), dim3(1024), 0, ctx->stream, d_keys, (unsigned)k);
     }
     KTLVO_HIP(ctx, hipGetLastError());
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
