@@ -400,6 +400,33 @@ def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
         ctx.detect_gftt(0, [(250, 170, 59, 39)], klib.gftt_params())   # ROI leaves the frame
 
 
+def test_gftt_all_negative_response(make_ctx, oracle, klib):
+    """Harris with k > 0 on a pure ramp: every response is negative (det = 0, trace > 0), so the ROI maximum is
+    negative and quality * max lies ABOVE it: goodFeaturesToTrack keeps nothing.  Small ROI (LDS selection) and
+    whole frame (global selection), against the oracle; then a ramp with one blob, whose few positive responses
+    must sort above the negative ones."""
+    W, H = 320, 200
+    ramp = np.tile((np.arange(W) * 0.7).astype(np.uint8), (H, 1))
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, ramp)
+    gp = klib.gftt_params(50, 0.01, 5.0, 3, 1, 0.04)
+    resp = ctx.corner_response(0, (40, 40, 59, 39), True, 0.04)
+    assert resp.max() < 0
+    assert np.array_equal(resp, oracle.corner_response(ramp, (40, 40, 59, 39), True, 0.04))
+    for roi in ((40, 40, 59, 39), (0, 0, W, H)):
+        (xy, rs), = ctx.detect_gftt(0, [roi], gp)
+        oxy, ors = oracle.good_features(ramp, roi, 50, 0.01, 5.0, True, 0.04)
+        assert len(xy) == 0 and len(oxy) == 0
+    img = ramp.copy()
+    yy, xx = np.mgrid[0:H, 0:W]
+    img[(yy - 100) ** 2 + (xx - 150) ** 2 < 36] = 255
+    ctx.upload_image(0, img)
+    for roi in ((120, 80, 60, 40), (0, 0, W, H)):
+        (xy, rs), = ctx.detect_gftt(0, [roi], gp)
+        oxy, ors = oracle.good_features(img, roi, 50, 0.01, 5.0, True, 0.04)
+        assert len(xy) > 0 and np.array_equal(xy, oxy) and np.array_equal(rs, ors)
+
+
 def test_gftt_reference_grid_and_full_frame(make_ctx, oracle, klib):
     W, H = 1242, 375
     scene = synth.CorridorScene(W, H, seed=3)

@@ -126,6 +126,27 @@ def test_tracker_matches_oracle_on_corridor(make_ctx, oracle, W, H):
     assert path > 5.0
 
 
+def test_published_messages_of_a_gpu_frame(make_ctx, klib):
+    """What the reference publishes per frame (featureTracking.cpp:656-664, visualOdometry.cpp:316-340), made
+    from the GPU path's own output: the three ROS 1 message bodies from the library's emitters equal the
+    independent struct.pack restatement byte for byte."""
+    from oracle import ros_wire as Wr
+    W, H = 1242, 375
+    scene = synth.CorridorScene(W, H, seed=0x5EED0001)
+    ctx = make_ctx()
+    for f in range(3):
+        L, R = scene.stereo_pair(f)
+        last, cur, kf = ctx.track_stereo_frame(L, R)
+    assert len(last) > 100
+    _, Tl, _ = ctx.estimate_pose(last, cur)
+    stamp = 1317617735.8837
+    assert klib.wire_depth_points(last, 7, stamp, None) == Wr.point_cloud2(
+        Wr.DEPTH_FIELDS, [tuple(r) for r in last.tolist()], 7, stamp, "")
+    assert klib.wire_image_points(cur, 7, stamp, None) == Wr.point_cloud2(
+        Wr.IMAGE_FIELDS, [tuple(r) for r in cur.tolist()], 7, stamp, "")
+    assert klib.wire_transform(Tl.reshape(16), 7, stamp, None) == Wr.transform_msg(Tl.reshape(16), 7, stamp, "")
+
+
 def test_tracker_edge_cases(make_ctx, klib):
     ctx = make_ctx()
     flat = np.full((375, 1242), 128, np.uint8)
