@@ -719,15 +719,19 @@ def main():
         ceil = issue_ceiling()
         if pmc and pmc.get("SQ_INSTS_VALU") and k3_avg_s > 0:
             clock = pmc.get("clock_ghz") or (ceil or {}).get("clock_ghz_in_probe") or 2.4
-            cyc_per_inst = 1024.0 * clock * 1e9 * k3_avg_s / pmc["SQ_INSTS_VALU"]
+            # shader cycles of one launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs; without it, clock x live duration
+            launch_cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0 if pmc.get("GRBM_GUI_ACTIVE") else clock * 1e9 * k3_avg_s
+            cyc_per_inst = 1024.0 * launch_cycles / pmc["SQ_INSTS_VALU"]
             valu = {"insts_per_feature": pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"],
                     "vmem_insts_per_feature": pmc.get("SQ_INSTS_VMEM", 0.0) / pmc["SQ_WAVES"],
                     "shader_clock_ghz": clock, "clock_source": "GRBM_GUI_ACTIVE" if pmc.get("clock_ghz") else "probe",
+                    "launch_cycles": launch_cycles,
                     "cycles_per_wave_inst_per_simd": cyc_per_inst,
                     "ceiling": ceil,
                     "issue_frac": (ceil["cycles_per_inst_lk_mix"] / cyc_per_inst) if ceil else None,
-                    "note": "achieved cycles per wave-instruction per SIMD against the measured issue cost of the "
-                            "kernel's instruction mix; counters from " + traffic_src}
+                    "note": "1024 SIMDs x shader cycles of a launch / SQ_INSTS_VALU, against the measured issue cost of "
+                            "the kernel's instruction mix (a fraction of 1 = every issue slot taken); counters from "
+                            + traffic_src}
         out = {
             "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
             "value": value,
