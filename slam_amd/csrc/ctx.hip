@@ -1,6 +1,7 @@
 // Context life cycle, stream handling, profiling events and error strings of libktlvo_hip.so.
 #include "ctx.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace ktlvo {
@@ -117,6 +118,10 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
     ktlvo_ctx *ctx = new ktlvo_ctx;
     ctx->cfg = *cfg;
     ctx->device = device_id;
+    {
+        const char *e = getenv("KTLVO_PYR_PER_LEVEL");
+        ctx->pyr_per_level = e && e[0] == '1';
+    }
 
     // level geometry: OpenCV's buildOpticalFlowPyramid rule
     int w = cfg->width, h = cfg->height;

@@ -91,6 +91,7 @@ struct ktlvo_ctx {
     int *d_idx = nullptr;   // max_points + 1 ints
     void *d_misc = nullptr; // corner / ransac work area
     size_t misc_bytes = 0;
+    bool pyr_per_level = false; // one pyrDown launch per level instead of the fused small-level kernel (A/B, tests)
     void *noalloc_scratch = nullptr; // this device's address of the fixed scratch array of ktlvo_detect_gftt_noalloc
     void *d_aux = nullptr;  // sort buffer and cell grid of whole-frame corner selection
     size_t aux_bytes = 0;

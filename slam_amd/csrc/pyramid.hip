@@ -144,6 +144,101 @@ __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotLi
     }
 }
 
+// ---- three levels in one launch ---------------------------------------------------------------------------
+// Levels first+1, first+2, first+3 from level `first`.  The small levels of a pyramid are a few tens of
+// kilobytes each, and a launch per level costs more in launch latency than in work; here a workgroup owns an
+// 8 x 8 tile of the LAST level and forms everything that tile depends on in LDS: an 85 x 85 region of the
+// source level, 41 x 41 of the first new level, 19 x 19 of the second (the halos are recomputed by the
+// neighbouring workgroups).  It writes its exclusive part of each level, 32 x 32, 16 x 16 and 8 x 8 pixels, each
+// with the pixels' reflect-101 copies in the level's frame, as pyr_down_u8 does.
+// pyrDown reflects at the edges of EACH source level, so an intermediate level's entries beyond the level are
+// not computed from mirrored sources (that differs when the level below has an even size) but copied from
+// their mirror images inside the level, which the same region holds.
+constexpr int TT = 8;                 // tile of the last level
+constexpr int R2 = 2 * TT + 3;        // 19: second new level, coordinates 2 x3 - 2 ...
+constexpr int R1 = 2 * R2 + 3;        // 41: first new level, coordinates 4 x3 - 6 ...
+constexpr int R0 = 2 * R1 + 3;        // 85: source level, coordinates 8 x3 - 14 ...
+
+// pixel (x, y) of level L and its single reflections into the frame (pyr_store_row's rule, per pixel)
+__device__ __forceinline__ void store_mirrored(const LevelDesc &L, int x, int y, uint8_t v) {
+    int xs[3], ys[3], nx = 0, ny = 0;
+    xs[nx++] = x;
+    if (x >= 1 && x <= PAD) xs[nx++] = -x;
+    if (x <= L.w - 2 && 2 * (L.w - 1) - x < L.w + PAD) xs[nx++] = 2 * (L.w - 1) - x;
+    ys[ny++] = y;
+    if (y >= 1 && y <= PAD) ys[ny++] = -y;
+    if (y <= L.h - 2 && 2 * (L.h - 1) - y < L.h + PAD) ys[ny++] = 2 * (L.h - 1) - y;
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) L.origin[(ptrdiff_t)ys[j] * L.pitch + xs[i]] = v;
+}
+
+// One pyrDown step inside LDS.  src: SR x SR bytes whose entry (0, 0) is source coordinate (2 ox - 2, 2 oy - 2);
+// dst: DR x DR bytes whose entry (0, 0) is destination coordinate (ox, oy).  Entries whose coordinate lies in the
+// destination level are computed (separably, through `tmp`), then the two rows and columns beyond each edge are
+// copied from their mirror images.
+template <int SR, int DR>
+__device__ __forceinline__ void lds_pyr_step(const uint8_t (*src)[SR + 3], uint8_t (*dst)[DR + 3], unsigned short *tmp,
+                                             int ox, int oy, int dw, int dh) {
+    const int tid = threadIdx.x;
+    // horizontal: tmp[r][c] for source row r, destination column c
+    for (int i = tid; i < SR * DR; i += 256) {
+        const int r = i / DR, c = i - r * DR;
+        const uint8_t *p = &src[r][2 * c];
+        tmp[i] = (unsigned short)(p[0] + p[4] + 4 * (p[1] + p[3]) + 6 * p[2]);
+    }
+    __syncthreads();
+    for (int i = tid; i < DR * DR; i += 256) {
+        const int r = i / DR, c = i - r * DR;
+        const int x = ox + c, y = oy + r;
+        if (x < 0 || y < 0 || x >= dw || y >= dh) continue;
+        const unsigned short *q = tmp + (2 * r) * DR + c;
+        const int v = q[0] + q[4 * DR] + 4 * (q[DR] + q[3 * DR]) + 6 * q[2 * DR];
+        dst[r][c] = (uint8_t)((v + 128) >> 8);
+    }
+    __syncthreads();
+    for (int i = tid; i < DR * DR; i += 256) {
+        const int r = i / DR, c = i - r * DR;
+        const int x = ox + c, y = oy + r;
+        if (x >= 0 && y >= 0 && x < dw && y < dh) continue;
+        if (x < -2 || y < -2 || x > dw + 1 || y > dh + 1) continue; // never read
+        const int mx = reflect101(x, dw) - ox, my = reflect101(y, dh) - oy;
+        if (mx >= 0 && my >= 0 && mx < DR && my < DR) dst[r][c] = dst[my][mx];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void pyr_down_tail3(const SlotDesc *slots, SlotList list, int first) {
+    const SlotDesc &S = slots[list.s[blockIdx.z]];
+    const LevelDesc L0 = S.lv[first], L1 = S.lv[first + 1], L2 = S.lv[first + 2], L3 = S.lv[first + 3];
+    const int x3 = blockIdx.x * TT, y3 = blockIdx.y * TT;
+    if (x3 >= L3.w || y3 >= L3.h) return;
+    __shared__ uint8_t s0[R0][R0 + 3], s1[R1][R1 + 3], s2[R2][R2 + 3], s3[TT][TT + 3];
+    __shared__ unsigned short tmp[R0 * R1];
+    const int tid = threadIdx.x;
+    const int x0 = 8 * x3 - 14, y0 = 8 * y3 - 14;
+    for (int i = tid; i < R0 * R0; i += 256) {
+        const int r = i / R0, c = i - r * R0;
+        s0[r][c] = L0.origin[(ptrdiff_t)reflect101(y0 + r, L0.h) * L0.pitch + reflect101(x0 + c, L0.w)];
+    }
+    __syncthreads();
+    lds_pyr_step<R0, R1>(s0, s1, tmp, 4 * x3 - 6, 4 * y3 - 6, L1.w, L1.h);
+    lds_pyr_step<R1, R2>(s1, s2, tmp, 2 * x3 - 2, 2 * y3 - 2, L2.w, L2.h);
+    lds_pyr_step<R2, TT>(s2, s3, tmp, x3, y3, L3.w, L3.h);
+    // exclusive parts: 32 x 32 of L1 at (4 x3, 4 y3), entry (6, 6) of s1; 16 x 16 of L2 at (2 x3, 2 y3), entry (2, 2) of s2
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int r = i >> 5, c = i & 31, x = 4 * x3 + c, y = 4 * y3 + r;
+        if (x < L1.w && y < L1.h) store_mirrored(L1, x, y, s1[r + 6][c + 6]);
+    }
+    {
+        const int r = tid >> 4, c = tid & 15, x = 2 * x3 + c, y = 2 * y3 + r;
+        if (x < L2.w && y < L2.h) store_mirrored(L2, x, y, s2[r + 2][c + 2]);
+    }
+    if (tid < TT * TT) {
+        const int r = tid >> 3, c = tid & 7, x = x3 + c, y = y3 + r;
+        if (x < L3.w && y < L3.h) store_mirrored(L3, x, y, s3[r][c]);
+    }
+}
+
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // calcSharrDeriv for every level of the listed slots in one launch: grid (row segments of level 0,
@@ -391,9 +486,19 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
         for (int i = 0; i < list.n; i++) list.s[i] = slots[base + i];
         {
             ProfScope ps(ctx, KTLVO_K_PYRDOWN);
-            for (int l = 0; l < top; l++) {
+            // level 0 -> 1 streams; with the reference's five levels and a handful of images (the per-frame path
+            // builds two), levels 2, 3 and 4 then come from ONE launch: three launches of a few workgroups each
+            // cost 25 us in launch latency there, the fused kernel 8.  For large batches the per-level launches are
+            // faster (the fused kernel recomputes halos through LDS: 0.14 against 0.09 ms for 256 images).
+            // (KTLVO_PYR_PER_LEVEL=1 in the environment at context creation keeps a launch per level: A/B and tests)
+            const bool tail = top == 4 && list.n <= 8 && !ctx->pyr_per_level;
+            for (int l = 0; l < (tail ? 1 : top); l++) {
                 dim3 grid((ctx->lw[l + 1] + PD_TW - 1) / PD_TW, (ctx->lh[l + 1] + PD_TH - 1) / PD_TH, list.n);
                 hipLaunchKernelGGL(pyr_down_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, l);
+            }
+            if (tail) {
+                dim3 grid((ctx->lw[4] + TT - 1) / TT, (ctx->lh[4] + TT - 1) / TT, list.n);
+                hipLaunchKernelGGL(pyr_down_tail3, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, 1);
             }
         }
         KTLVO_HIP(ctx, hipGetLastError());

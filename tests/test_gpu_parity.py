@@ -500,6 +500,44 @@ def test_get_optical_flow_matches_composition(make_ctx, oracle):
     assert 100 < len(idx) < 1500
 
 
+@pytest.mark.parametrize("size", [(1241, 376), (1242, 375), (640, 360), (353, 370), (368, 353), (1920, 1080)])
+def test_fused_small_levels_equal_per_level_launches(make_ctx, oracle, size):
+    """Levels 2-4 from ONE launch (pyr_down_tail3) against a launch per level (KTLVO_PYR_PER_LEVEL=1) and against
+    the oracle: identical levels, and identical LK results for points hugging and leaving every edge, which read
+    the levels' reflect-101 frames at all five levels."""
+    W, H = size
+    rng = np.random.default_rng(W * 7 + H)
+    a = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    b = np.roll(a, (1, -2), (0, 1))
+    os.environ["KTLVO_PYR_PER_LEVEL"] = "1"
+    try:
+        ref = make_ctx(width=W, height=H, num_slots=2, max_points=4096)
+    finally:
+        del os.environ["KTLVO_PYR_PER_LEVEL"]
+    new = make_ctx(width=W, height=H, num_slots=2, max_points=4096)
+    po = oracle.Pyramid(a, 4, 21)
+    for ctx in (ref, new):
+        ctx.upload_image(0, a)
+        ctx.upload_image(1, b)
+        ctx.build_pyramids([0, 1])
+        assert ctx.pyramid_levels(0) == po.max_level == 4
+    for l in range(5):
+        lv = po.level(l)
+        assert np.array_equal(new.download_level(0, l), lv), l
+        assert np.array_equal(ref.download_level(0, l), lv), l
+        assert np.array_equal(new.download_scharr(0, l, lv.shape[1], lv.shape[0]), po.deriv(l)), l
+    n = 3000
+    edge = rng.integers(0, 4, n)
+    t_ = rng.uniform(0, 1, n)
+    off = rng.uniform(-24, 24, n)
+    x = np.where(edge == 0, off, np.where(edge == 1, W - 1 + off, t_ * W))
+    y = np.where(edge == 2, off, np.where(edge == 3, H - 1 + off, t_ * H))
+    pts = np.stack([x, y], 1).astype(np.float32)
+    ra, rb = ref.pyrlk(0, 1, pts), new.pyrlk(0, 1, pts)
+    assert all(np.array_equal(p, q) for p, q in zip(ra, rb))
+    assert 0.05 < ra[1].mean() < 1.0
+
+
 def test_batched_upload_equals_per_frame_upload(make_ctx):
     """ktlvo_upload_images (one DMA, one ingest launch) fills the slots exactly as n ktlvo_upload_image calls do,
     from pageable and from pinned memory, into slots given in any order."""
