@@ -427,6 +427,29 @@ def test_gftt_all_negative_response(make_ctx, oracle, klib):
         assert len(xy) > 0 and np.array_equal(xy, oxy) and np.array_equal(rs, ors)
 
 
+def test_gftt_large_rois_variants(make_ctx, oracle, klib):
+    """Device-side selection for ROIs beyond the LDS path: no minimum distance (the first N of the sorted list),
+    several large ROIs in one call, a fractional minimum distance, Harris and min-eigenvalue, a count no frame
+    can reach (the greedy pass runs to the end of the list), a featureless frame."""
+    W, H = 700, 420
+    img = synth.texture_image(W, H, seed=99, periods=(37.0, 13.0, 5.0), noise=True)
+    ctx = make_ctx(width=W, height=H, max_points=30000)
+    ctx.upload_image(0, img)
+    rois = [(0, 0, W, H), (10, 20, 300, 200), (350, 100, 333, 311)]
+    for gp in (klib.gftt_params(3000, 0.01, 0.0, 3, 0, 0.0), klib.gftt_params(1500, 0.02, 3.7, 3, 1, 0.04),
+               klib.gftt_params(20000, 0.001, 6.0, 3, 0, 0.0), klib.gftt_params(500, 0.3, 25.0, 3, 1, 0.0)):
+        got = ctx.detect_gftt(0, rois, gp)
+        for roi, (xy, rs) in zip(rois, got):
+            oxy, ors = oracle.good_features(img, roi, gp.max_corners, gp.quality, gp.min_dist, bool(gp.use_harris),
+                                            gp.harris_k)
+            assert np.array_equal(xy, np.asarray(oxy, np.float32).reshape(-1, 2)), (roi, gp.min_dist)
+            assert np.array_equal(rs, np.asarray(ors, np.float32))
+        assert len(got[0][0]) > 100
+    ctx.upload_image(0, np.full((H, W), 77, np.uint8))
+    (xy, rs), = ctx.detect_gftt(0, [(0, 0, W, H)], klib.gftt_params(100, 0.01, 5.0, 3, 0, 0.0))
+    assert len(xy) == 0
+
+
 def test_gftt_reference_grid_and_full_frame(make_ctx, oracle, klib):
     W, H = 1242, 375
     scene = synth.CorridorScene(W, H, seed=3)
