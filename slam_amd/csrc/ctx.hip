@@ -195,9 +195,14 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
         if (ctx->stage.d_buf[i]) (void)hipFree(ctx->stage.d_buf[i]);
         if (ctx->stage.done[i]) (void)hipEventDestroy(ctx->stage.done[i]);
     }
-    if (ctx->stage.d_batch) (void)hipFree(ctx->stage.d_batch);
-    if (ctx->stage.h_batch) (void)hipHostFree(ctx->stage.h_batch);
-    if (ctx->stage.batch_done) (void)hipEventDestroy(ctx->stage.batch_done);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->stage.d_batch[k]) (void)hipFree(ctx->stage.d_batch[k]);
+        if (ctx->stage.h_batch[k]) (void)hipHostFree(ctx->stage.h_batch[k]);
+        if (ctx->stage.batch_done[k]) (void)hipEventDestroy(ctx->stage.batch_done[k]);
+        if (ctx->stage.copy_done[k]) (void)hipEventDestroy(ctx->stage.copy_done[k]);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (int i = 0; i < 4; i++) if (ctx->d_pts[i]) (void)hipFree(ctx->d_pts[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_err) (void)hipFree(ctx->d_err);

@@ -54,11 +54,16 @@ struct StageRing {
     hipEvent_t done[N] = {nullptr, nullptr, nullptr, nullptr};
     bool used[N] = {false, false, false, false};
     int next = 0;
-    // ktlvo_upload_images: one device buffer (and, for pageable sources, one pinned buffer) for a whole batch
-    uint8_t *d_batch = nullptr, *h_batch = nullptr;
-    size_t batch_bytes = 0;
-    hipEvent_t batch_done = nullptr;
-    bool batch_used = false;
+    // Whole batches (ktlvo_upload_images, and the stereo pair of the per-frame path): two device staging buffers
+    // (and, for pageable sources, two pinned ones) used in turn, each made on its first use.  ktlvo_upload_images
+    // issues its DMA on the context's copy stream, so the transfer of one batch runs while the kernels queued
+    // before the call still work; the ingest launch that unpacks it waits for it on the context's stream.
+    uint8_t *d_batch[2] = {nullptr, nullptr}, *h_batch[2] = {nullptr, nullptr};
+    size_t batch_bytes = 0;                          // size of every buffer that exists
+    hipEvent_t batch_done[2] = {nullptr, nullptr};   // the ingest launch reading d_batch[k] has run
+    hipEvent_t copy_done[2] = {nullptr, nullptr};    // the DMA into d_batch[k] has landed
+    bool batch_used[2] = {false, false};
+    int batch_next = 0;
 };
 
 struct TrackerState; // tracker.hip
@@ -70,6 +75,7 @@ struct ktlvo_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr; // stream in use (own_stream or the caller's)
+    hipStream_t copy_stream = nullptr; // host-to-device DMA of ktlvo_upload_images (made on first use)
     std::string last_error;
 
     // image slots

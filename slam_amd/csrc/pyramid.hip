@@ -17,33 +17,45 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 }
 
 // Ingest: copies a w x h image (row stride `stride`) into level 0 of a slot and fills the reflect-101 frame
-// in the same pass.  A thread makes four consecutive bytes of the padded plane (one aligned word store; the
-// plane's origin, pitch and PAD are multiples of four); away from the left and right edges its four source
-// bytes are consecutive too.
-__device__ __forceinline__ void ingest_quad(const LevelDesc &L, const uint8_t *src, int stride, int x, int y) {
-    if (x >= L.w + PAD || y >= L.h + PAD) return;
-    const uint8_t *row = src + (size_t)reflect101(y, L.h) * stride;
-    uint32_t v;
-    if (x >= 0 && x + 3 < L.w) {
-        v = (uint32_t)row[x] | ((uint32_t)row[x + 1] << 8) | ((uint32_t)row[x + 2] << 16) | ((uint32_t)row[x + 3] << 24);
-    } else {
-        v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * k);
+// in the same pass.  A thread makes sixteen consecutive bytes of the padded plane (one aligned 16-byte store;
+// the plane's origin, pitch and PAD are multiples of sixteen); away from the left and right edges its sixteen
+// source bytes are consecutive too and come in one load, at whatever byte address the row starts (global
+// loads need no alignment on this target).  Threads are numbered along the rows, `groups` of them per row.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ void ingest_16(const LevelDesc &L, const uint8_t *src, int stride, int groups, uint32_t i) {
+    typedef const __attribute__((address_space(1))) uint8_t *gsrc;
+    typedef __attribute__((address_space(1))) uint8_t *gdst;
+    const int yy = (int)(i / (uint32_t)groups);
+    const int x = (int)(i - (uint32_t)yy * (uint32_t)groups) * 16 - PAD, y = yy - PAD;
+    if (y >= L.h + PAD) return;
+    gsrc row = (gsrc)src + (size_t)reflect101(y, L.h) * stride;
+    gdst out = (gdst)L.origin + (ptrdiff_t)y * L.pitch + x;
+    if (x >= 0 && x + 15 < L.w) {
+        *(__attribute__((address_space(1))) u32x4 *)out = *(const __attribute__((address_space(1))) u32x4_a1 *)(row + x);
+        return;
     }
-    *(uint32_t *)(L.origin + (ptrdiff_t)y * L.pitch + x) = v;
+    uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k >> 2] |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * (k & 3));
+    if (x + 15 < L.w + PAD) {
+        *(__attribute__((address_space(1))) u32x4 *)out = u32x4{v[0], v[1], v[2], v[3]};
+    } else { // the plane's rows end at w + PAD: what lies beyond stays as it is
+        for (int k = 0; k < 16 && x + k < L.w + PAD; k++) out[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+    }
 }
+__host__ __device__ inline int ingest_groups(int w) { return (w + 2 * PAD + 15) / 16; }
 __global__ __launch_bounds__(256) void ingest_pad_u8(const SlotDesc *slots, int slot, const uint8_t *src, int stride) {
     const LevelDesc L = slots[slot].lv[0];
-    ingest_quad(L, src, stride, (int)(blockIdx.x * 256 + (threadIdx.x & 63) * 4) - PAD, (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PAD);
+    ingest_16(L, src, stride, ingest_groups(L.w), blockIdx.x * 256 + threadIdx.x);
 }
 // The same for a batch: image z of a contiguous device buffer (image_stride bytes apart) goes into slot list.s[z].
 __global__ __launch_bounds__(256) void ingest_pad_batch_u8(const SlotDesc *slots, SlotList list, const uint8_t *src,
                                                            size_t image_stride, int stride) {
     const LevelDesc L = slots[list.s[blockIdx.z]].lv[0];
-    ingest_quad(L, src + blockIdx.z * image_stride, stride, (int)(blockIdx.x * 256 + (threadIdx.x & 63) * 4) - PAD,
-                (int)(blockIdx.y * 4 + (threadIdx.x >> 6)) - PAD);
+    ingest_16(L, src + blockIdx.z * image_stride, stride, ingest_groups(L.w), blockIdx.x * 256 + threadIdx.x);
 }
+static inline unsigned ingest_blocks(int w, int h) { return (unsigned)(((size_t)ingest_groups(w) * (h + 2 * PAD) + 255) / 256); }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // Plane pointers come out of a descriptor in memory, so the compiler would treat them as generic
@@ -51,7 +63,6 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) uint8_t *gbyte;
 typedef const __attribute__((address_space(1))) uint8_t *gcbyte;
 typedef __attribute__((address_space(1))) uint32_t *gword;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // the same sixteen bytes at an address that is only dword aligned (rows start at x - 4 for any x that is a
 // multiple of 4): global_load_dwordx4 takes such addresses, and the type says so to the compiler
 typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256) void scharr_planes(const SlotDesc *slots, Slot
 }
 
 static int launch_ingest(ktlvo_ctx *ctx, int slot, const uint8_t *d_src, int stride) {
-    dim3 grid((ctx->cfg.width + 2 * PAD + 255) / 256, (ctx->cfg.height + 2 * PAD + 3) / 4, 1);
+    dim3 grid(ingest_blocks(ctx->cfg.width, ctx->cfg.height), 1, 1);
     hipLaunchKernelGGL(ingest_pad_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, d_src, stride);
     KTLVO_HIP(ctx, hipGetLastError());
     ctx->built[slot] = 0;
@@ -373,9 +384,43 @@ extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, 
     return KTLVO_OK;
 }
 
+namespace ktlvo {
+// Staging buffer k of the batch uploads, at least `bytes` large and no longer read by an earlier ingest launch.
+static int stage_take(ktlvo_ctx *ctx, size_t bytes, int k, bool want_pinned) {
+    StageRing &r = ctx->stage;
+    if (bytes > r.batch_bytes) { // grow: every buffer goes, and each comes back on its next use
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->copy_stream) KTLVO_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        for (int i = 0; i < 2; i++) {
+            if (r.d_batch[i]) KTLVO_HIP(ctx, hipFree(r.d_batch[i]));
+            r.d_batch[i] = nullptr;
+            if (r.h_batch[i]) KTLVO_HIP(ctx, hipHostFree(r.h_batch[i]));
+            r.h_batch[i] = nullptr;
+            r.batch_used[i] = false;
+        }
+        r.batch_bytes = bytes;
+    }
+    if (!r.d_batch[k]) KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch[k], r.batch_bytes));
+    if (want_pinned && !r.h_batch[k]) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_batch[k], r.batch_bytes, hipHostMallocDefault));
+    if (!r.batch_done[k]) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.batch_done[k], hipEventDisableTiming));
+    if (!r.copy_done[k]) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.copy_done[k], hipEventDisableTiming));
+    if (r.batch_used[k]) KTLVO_HIP(ctx, hipEventSynchronize(r.batch_done[k]));
+    return KTLVO_OK;
+}
+static bool is_pinned(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost) return true;
+    (void)hipGetLastError(); // an unregistered pointer is reported as an error by some runtimes
+    return false;
+}
+} // namespace ktlvo
+
 // A whole batch of frames in one DMA and one ingest launch.  A per-frame upload moves 466 KB per DMA for a
 // KITTI-sized frame, which the host link serves at well under half its rate; one transfer of the whole batch
-// runs at the link's rate, and issued on a context of its own it overlaps another context's kernels.
+// runs at the link's rate.  The DMA goes to the context's copy stream and only the ingest launch, on the
+// context's stream, waits for it: a caller that uploads the next batch right after queueing the work on the
+// current one has the transfer run under that work, with one context and one set of slots (the ingest launch
+// overwrites the slots in stream order, after the kernels that still read them).
 extern "C" int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, const uint8_t *imgs, int w, int h, int stride,
                                    size_t image_stride) {
     if (!ctx || n < 0 || (n > 0 && (!slots || !imgs))) return KTLVO_ERR_INVALID;
@@ -388,76 +433,59 @@ extern "C" int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, cons
         if (!slot_ok(ctx, slots[i])) return KTLVO_ERR_INVALID;
     const size_t bytes = image_stride * (size_t)(n - 1) + (size_t)stride * (h - 1) + w;
     StageRing &r = ctx->stage;
-    if (bytes > r.batch_bytes) {
-        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (r.d_batch) KTLVO_HIP(ctx, hipFree(r.d_batch));
-        if (r.h_batch) KTLVO_HIP(ctx, hipHostFree(r.h_batch));
-        r.d_batch = r.h_batch = nullptr;
-        r.batch_bytes = 0;
-        KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch, bytes));
-        r.batch_bytes = bytes;
-    }
-    if (!r.batch_done) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.batch_done, hipEventDisableTiming));
-    if (r.batch_used) KTLVO_HIP(ctx, hipEventSynchronize(r.batch_done)); // the previous batch has left the staging buffers
-    hipPointerAttribute_t attr;
+    if (!ctx->copy_stream) KTLVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    const bool pinned = is_pinned(imgs);
+    const int k = r.batch_next;
+    int rc = stage_take(ctx, bytes, k, !pinned);
+    if (rc != KTLVO_OK) return rc;
+    r.batch_next = k ^ 1;
     const uint8_t *src = imgs;
-    if (!(hipPointerGetAttributes(&attr, imgs) == hipSuccess && attr.type == hipMemoryTypeHost)) {
-        (void)hipGetLastError();
-        if (!r.h_batch) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_batch, r.batch_bytes, hipHostMallocDefault));
-        memcpy(r.h_batch, imgs, bytes); // pageable source: staged, so the call returns with the caller's buffer free
-        src = r.h_batch;
+    if (!pinned) { // pageable source: staged, so the call returns with the caller's buffer free
+        memcpy(r.h_batch[k], imgs, bytes);
+        src = r.h_batch[k];
     }
-    KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch[k], src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    KTLVO_HIP(ctx, hipEventRecord(r.copy_done[k], ctx->copy_stream));
+    KTLVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, r.copy_done[k], 0));
     SlotList list;
     list.n = n;
     for (int i = 0; i < n; i++) list.s[i] = slots[i];
-    dim3 grid((w + 2 * PAD + 255) / 256, (h + 2 * PAD + 3) / 4, n);
-    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, r.d_batch, image_stride, stride);
+    dim3 grid(ingest_blocks(w, h), 1, n);
+    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, r.d_batch[k], image_stride, stride);
     KTLVO_HIP(ctx, hipGetLastError());
-    KTLVO_HIP(ctx, hipEventRecord(r.batch_done, ctx->stream));
-    r.batch_used = true;
+    KTLVO_HIP(ctx, hipEventRecord(r.batch_done[k], ctx->stream));
+    r.batch_used[k] = true;
     for (int i = 0; i < n; i++) { ctx->built[slots[i]] = 0; ctx->deriv_ok[slots[i]] = 0; }
     return KTLVO_OK;
 }
 
 namespace ktlvo {
 // Two frames (a stereo pair) into two slots with one ingest launch, and for pageable sources one DMA: the
-// per-frame path's set-up cost is a handful of runtime calls, and this halves them.
+// per-frame path's set-up cost is a handful of runtime calls, and this halves them.  Everything stays on the
+// context's stream (a frame call waits for its own upload anyway, and a second stream would add two events).
 int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const uint8_t *b, int w, int h) {
     const size_t bytes = (size_t)w * h, img_stride = (bytes + 255) & ~(size_t)255;
     StageRing &r = ctx->stage;
-    if (2 * img_stride > r.batch_bytes) {
-        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (r.d_batch) KTLVO_HIP(ctx, hipFree(r.d_batch));
-        if (r.h_batch) KTLVO_HIP(ctx, hipHostFree(r.h_batch));
-        r.d_batch = r.h_batch = nullptr;
-        r.batch_bytes = 0;
-        KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch, 2 * img_stride));
-        r.batch_bytes = 2 * img_stride;
-    }
-    if (!r.batch_done) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.batch_done, hipEventDisableTiming));
-    if (r.batch_used) KTLVO_HIP(ctx, hipEventSynchronize(r.batch_done));
-    hipPointerAttribute_t attr;
-    const bool pinned = hipPointerGetAttributes(&attr, a) == hipSuccess && attr.type == hipMemoryTypeHost &&
-                        hipPointerGetAttributes(&attr, b) == hipSuccess && attr.type == hipMemoryTypeHost;
+    const bool pinned = is_pinned(a) && is_pinned(b);
+    int rc = stage_take(ctx, 2 * img_stride, 0, !pinned);
+    if (rc != KTLVO_OK) return rc;
+    uint8_t *d = r.d_batch[0];
     if (pinned) { // read by DMA where they lie
-        KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch, a, bytes, hipMemcpyHostToDevice, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch + img_stride, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(d + img_stride, b, bytes, hipMemcpyHostToDevice, ctx->stream));
     } else {
-        (void)hipGetLastError();
-        if (!r.h_batch) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_batch, r.batch_bytes, hipHostMallocDefault));
-        memcpy(r.h_batch, a, bytes);
-        memcpy(r.h_batch + img_stride, b, bytes);
-        KTLVO_HIP(ctx, hipMemcpyAsync(r.d_batch, r.h_batch, img_stride + bytes, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(r.h_batch[0], a, bytes);
+        memcpy(r.h_batch[0] + img_stride, b, bytes);
+        KTLVO_HIP(ctx, hipMemcpyAsync(d, r.h_batch[0], img_stride + bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     SlotList list;
     list.n = 2;
     list.s[0] = slot_a; list.s[1] = slot_b;
-    dim3 grid((w + 2 * PAD + 255) / 256, (h + 2 * PAD + 3) / 4, 2);
-    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, r.d_batch, img_stride, w);
+    dim3 grid(ingest_blocks(w, h), 1, 2);
+    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, d, img_stride, w);
     KTLVO_HIP(ctx, hipGetLastError());
-    KTLVO_HIP(ctx, hipEventRecord(r.batch_done, ctx->stream));
-    r.batch_used = true;
+    KTLVO_HIP(ctx, hipEventRecord(r.batch_done[0], ctx->stream));
+    r.batch_used[0] = true;
     ctx->built[slot_a] = ctx->built[slot_b] = 0;
     ctx->deriv_ok[slot_a] = ctx->deriv_ok[slot_b] = 0;
     return KTLVO_OK;

@@ -588,6 +588,53 @@ def test_batched_upload_equals_per_frame_upload(make_ctx):
     assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
 
 
+def test_batch_upload_runs_ahead_of_queued_work(make_ctx, klib):
+    """ktlvo_upload_images puts its DMA on the context's copy stream and unpacks on the context's stream.  A caller
+    that never waits (upload, pyramids, track, again with the next batch into the SAME slots, ...) gets, for every
+    batch, the result of a context that is waited for after every call; pageable and pinned sources, batches of
+    changing size (the staging buffers grow), and a per-frame upload in between."""
+    import torch
+    W, H, n = 640, 360, 6
+    rng = np.random.default_rng(21)
+    from slam_amd.synth import texture_image
+    base = texture_image(W + 64, H + 64, seed=21)
+    a, b = (make_ctx(width=W, height=H, num_slots=n, max_points=1500) for _ in range(2))
+    NF = 1500
+    pts = np.stack([rng.uniform(0, W, NF), rng.uniform(0, H, NF)], 1).astype(np.float32)
+    d_prev = torch.from_numpy(np.tile(pts, (n - 1, 1))).cuda()
+    lk = klib.lk_params()
+    batches, keep = [], []
+    for rep in range(7):
+        m = (3, 6, 4, 6, 2, 6, 5)[rep]
+        imgs = np.stack([np.ascontiguousarray(base[4 * rep + 3 * i:4 * rep + 3 * i + H, rep + 5 * i:rep + 5 * i + W])
+                         for i in range(m)])
+        batches.append(imgs)
+    outs = [tuple((torch.zeros((n - 1) * NF, 2, device="cuda"), torch.zeros((n - 1) * NF, dtype=torch.uint8, device="cuda"),
+                   torch.zeros((n - 1) * NF, device="cuda")) for _ in batches) for _ in range(2)]
+    for which, ctx in enumerate((a, b)):
+        for rep, imgs in enumerate(batches):
+            m = len(imgs)
+            src = imgs
+            if rep % 2:
+                keep.append(torch.from_numpy(imgs).pin_memory())   # must outlive the DMA
+                src = keep[-1].numpy()
+            ctx.upload_images(list(range(m)), src)
+            if rep == 3:
+                ctx.upload_image(1, imgs[0])
+            ctx.build_pyramids(list(range(m)))
+            o = outs[which][rep]
+            ctx.pyrlk_batch_dev(list(range(m - 1)), list(range(1, m)), d_prev.data_ptr(), NF, o[0].data_ptr(),
+                                o[1].data_ptr(), o[2].data_ptr(), lk)
+            if which == 0:
+                ctx.sync()
+        ctx.sync()
+    for rep, imgs in enumerate(batches):
+        k = (len(imgs) - 1) * NF
+        for x, y in zip(outs[0][rep], outs[1][rep]):
+            assert torch.equal(x[:k], y[:k]), rep
+        assert int(outs[0][rep][1][:k].sum()) > k // 2
+
+
 # ---------------------------------------------------------------- RANSAC ----------------------
 def test_ransac_score_counts_exact(make_ctx, oracle):
     g = np.load(os.path.join(GOLD, "ransac_400.npz"))
