@@ -168,8 +168,8 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
     }
     const size_t np = (size_t)cfg->max_points;
     for (int i = 0; i < 4 && ok; i++) ok = hipMalloc((void **)&ctx->d_pts[i], np * 2 * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&ctx->d_status, 2 * np) == hipSuccess; // two lists: batched stereo/temporal LK
-    ok = ok && hipMalloc((void **)&ctx->d_err, 2 * np * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&ctx->d_status, 4 * np) == hipSuccess; // four lists: the frame path's second LK launch
+    ok = ok && hipMalloc((void **)&ctx->d_err, 4 * np * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&ctx->d_idx, (np + 1) * sizeof(int)) == hipSuccess;
     ok = ok && corner_noalloc_init(ctx) == KTLVO_OK;
     if (!ok) {

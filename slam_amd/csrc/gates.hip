@@ -26,18 +26,31 @@ struct GateArgs {
     float *gdst[MAX_GATHER];       // ... into these
 };
 
+struct GateBounds {
+    float x_lo, x_hi, y_lo, y_hi;
+    double max_track_dis;
+};
+// getOpticalFlow's keep predicate (:223-248) for point i of the lists f1 (start), f2 (forward track), f3 (f2 tracked back)
+__device__ __forceinline__ bool fb_keep(const GateBounds &b, const float *f1, const float *f2, const float *f3, float y_threshold,
+                                        int i) {
+    const float x1 = f1[2 * i], y1 = f1[2 * i + 1], x2 = f2[2 * i], y2 = f2[2 * i + 1];
+    const float cx = f3[2 * i], cy = f3[2 * i + 1];
+    const float s = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2);
+    const double trackDis = sqrt((double)s);
+    const bool drop = trackDis > b.max_track_dis || x2 < b.x_lo || x2 > b.x_hi || y2 < b.y_lo || y2 > b.y_hi ||
+                      x1 - cx > 5.f || y1 - cy > y_threshold;
+    return !drop;
+}
+// the circular check's predicate (:486-501); std::abs() wraps the comparison in the reference, so the test is one-sided
+__device__ __forceinline__ bool circular_keep(const float *pcr, const float *clr, int i) {
+    return (pcr[2 * i] - clr[2 * i] < 2.f) && (pcr[2 * i + 1] - clr[2 * i + 1] < 2.f);
+}
 __device__ __forceinline__ bool gate_keep(const GateArgs &a, int i) {
     if (a.mode == 0) {
-        const float x1 = a.f1[2 * i], y1 = a.f1[2 * i + 1], x2 = a.f2[2 * i], y2 = a.f2[2 * i + 1];
-        const float cx = a.f3[2 * i], cy = a.f3[2 * i + 1];
-        const float s = (x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2);
-        const double trackDis = sqrt((double)s);
-        const bool drop = trackDis > a.max_track_dis || x2 < a.x_lo || x2 > a.x_hi || y2 < a.y_lo || y2 > a.y_hi ||
-                          x1 - cx > 5.f || y1 - cy > a.y_threshold;
-        return !drop;
+        const GateBounds b = {a.x_lo, a.x_hi, a.y_lo, a.y_hi, a.max_track_dis};
+        return fb_keep(b, a.f1, a.f2, a.f3, a.y_threshold, i);
     }
-    // std::abs() wraps the comparison in the reference, so the test is one-sided
-    return (a.f1[2 * i] - a.f2[2 * i] < 2.f) && (a.f1[2 * i + 1] - a.f2[2 * i + 1] < 2.f);
+    return circular_keep(a.f1, a.f2, i);
 }
 
 // One workgroup walks the list in chunks of 1024 and keeps a running output offset, so the
@@ -74,6 +87,82 @@ __global__ __launch_bounds__(1024) void gate_compact(GateArgs a) {
         __syncthreads();
     }
     if (tid == 0) *a.n_keep = base;
+}
+
+// The three gates of a frame (circular check, then getOpticalFlow's gate with y threshold 1 on the stereo pair
+// and with y threshold 5 on the temporal pair, :486-515) in one pass over lists that are all indexed by the
+// frame's start points: a point's tracks depend on nothing but its images and its start, so every track a later
+// gate needs can be made before the earlier gate has spoken, and the gates only decide which points go on.
+// Output is what three gate_compact launches with gathers in between produce: K1 = start indices kept by
+// the first gate, K2 = positions in that list kept by the second, K3 = positions in the second list kept by the
+// third, and the survivors' start points, temporal tracks and stereo tracks.
+struct FrameGateArgs {
+    const float *A, *B, *C;     // start points in the last left image, their tracks into last right and current left
+    const float *D, *E;         // B tracked into current right, C tracked into current right
+    const float *CHK, *CHKB;    // B and C tracked back into the last left image
+    int n;
+    GateBounds b;
+    int *K1, *K2, *K3, *cnt;    // cnt[0..2] = list lengths
+    float *U1, *U2, *U3;        // A, C, B of the points that pass all three
+};
+__global__ __launch_bounds__(1024) void frame_gates(FrameGateArgs a) {
+    __shared__ int wave_cnt[3][16];
+    __shared__ int base[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 3) base[tid] = 0;
+    __syncthreads();
+    for (int start = 0; start < a.n; start += 1024) {
+        const int i = start + tid;
+        bool k[3];
+        k[0] = i < a.n && circular_keep(a.D, a.E, i);
+        k[1] = k[0] && fb_keep(a.b, a.A, a.B, a.CHK, 1.f, i);
+        k[2] = k[1] && fb_keep(a.b, a.A, a.C, a.CHKB, 5.f, i);
+        int before[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            const unsigned long long m = __ballot(k[g]);
+            before[g] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[g][wave] = __popcll(m);
+        }
+        __syncthreads();
+        int o[3];
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            int off = base[g];
+            for (int w = 0; w < wave; w++) off += wave_cnt[g][w];
+            o[g] = off + before[g];
+        }
+        if (k[0]) a.K1[o[0]] = i;
+        if (k[1]) a.K2[o[1]] = o[0];
+        if (k[2]) {
+            a.K3[o[2]] = o[1];
+            a.U1[2 * o[2]] = a.A[2 * i]; a.U1[2 * o[2] + 1] = a.A[2 * i + 1];
+            a.U2[2 * o[2]] = a.C[2 * i]; a.U2[2 * o[2] + 1] = a.C[2 * i + 1];
+            a.U3[2 * o[2]] = a.B[2 * i]; a.U3[2 * o[2] + 1] = a.B[2 * i + 1];
+        }
+        __syncthreads();
+        if (tid < 3) {
+            int t = 0;
+            for (int w = 0; w < 16; w++) t += wave_cnt[tid][w];
+            base[tid] += t;
+        }
+        __syncthreads();
+    }
+    if (tid < 3) a.cnt[tid] = base[tid];
+}
+
+int launch_frame_gates(ktlvo_ctx *ctx, const float *dA, const float *dB, const float *dC, const float *dD, const float *dE,
+                       const float *dCHK, const float *dCHKB, int n, int *dK1, int *dK2, int *dK3, int *d_cnt, float *dU1,
+                       float *dU2, float *dU3) {
+    FrameGateArgs a;
+    a.A = dA; a.B = dB; a.C = dC; a.D = dD; a.E = dE; a.CHK = dCHK; a.CHKB = dCHKB; a.n = n;
+    a.b.x_lo = (float)ctx->cfg.x_boundary; a.b.x_hi = (float)(ctx->cfg.width - ctx->cfg.x_boundary);
+    a.b.y_lo = (float)ctx->cfg.y_boundary; a.b.y_hi = (float)(ctx->cfg.height - ctx->cfg.y_boundary);
+    a.b.max_track_dis = ctx->cfg.max_track_dis;
+    a.K1 = dK1; a.K2 = dK2; a.K3 = dK3; a.cnt = d_cnt; a.U1 = dU1; a.U2 = dU2; a.U3 = dU3;
+    hipLaunchKernelGGL(frame_gates, dim3(1), dim3(1024), 0, ctx->stream, a);
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
 }
 
 int launch_fb_gate(ktlvo_ctx *ctx, const float *d_f1, const float *d_f2, const float *d_f1chk, int n, const int *d_n,

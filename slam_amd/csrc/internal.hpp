@@ -15,6 +15,9 @@ int launch_fb_gate(ktlvo_ctx *ctx, const float *d_f1, const float *d_f2, const f
                    int y_threshold, int *d_keep_idx, int *d_n_keep, const Gather &g);
 int launch_circular_gate(ktlvo_ctx *ctx, const float *d_pcr, const float *d_clr, int n, int *d_keep_idx,
                          int *d_n_keep, const Gather &g);
+int launch_frame_gates(ktlvo_ctx *ctx, const float *dA, const float *dB, const float *dC, const float *dD, const float *dE,
+                       const float *dCHK, const float *dCHKB, int n, int *dK1, int *dK2, int *dK3, int *d_cnt, float *dU1,
+                       float *dU2, float *dU3);
 int device_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float *d_f1, int n_cap, const int *d_n,
                             int y_threshold, float *d_f2, float *d_chk, int *d_keep_idx, int *d_n_keep,
                             const Gather &g);

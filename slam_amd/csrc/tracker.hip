@@ -4,8 +4,8 @@
 //
 // Differences from the reference that do not change results: each image's pyramid is built once
 // and the cur -> last hand-over is a slot swap (the reference rebuilds 16 pyramids per frame for 4
-// distinct images); the 8 LK calls of a frame become 3 launches (see the frame function) with the
-// gating and compaction between them done on the device, so the host synchronises once per frame.
+// distinct images); the 8 LK calls of a frame become 2 launches (see the frame function) with the
+// gating and compaction after them done on the device, so the host synchronises once per frame.
 #include "ctx.hpp"
 #include "internal.hpp"
 
@@ -25,8 +25,7 @@ struct TrackerState {
     // point lists (2N floats each).  h_io is its pinned host image; the start points go up through it too.
     int *d_out = nullptr;
     int *h_io = nullptr;
-    enum { A = 0, BC = 1 /* two lists */, DE = 3 /* two lists */, S1 = 5, F2, CHK /* two lists */, CHKB, T1, T2, G2, G3, CHK3,
-           NLIST };
+    enum { A = 0, BC = 1 /* two lists */, DE = 3 /* four lists */, NLIST = 7 };
     static size_t out_ints(size_t n) { return 8 + 9 * n; }
     float *list(int i, int cap) const { return d_buf + (size_t)i * cap * 2; }
 };
@@ -152,18 +151,20 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     const int CAP = c.max_points;
     typedef TrackerState TS;
     float *dA = t->list(TS::A, CAP), *dBC = t->list(TS::BC, CAP), *dDE = t->list(TS::DE, CAP);
-    float *dS1 = t->list(TS::S1, CAP), *dF2 = t->list(TS::F2, CAP), *dCHK = t->list(TS::CHK, CAP);
-    float *dCHKB = t->list(TS::CHKB, CAP), *dT1 = t->list(TS::T1, CAP), *dT2 = t->list(TS::T2, CAP);
-    float *dG2 = t->list(TS::G2, CAP), *dG3 = t->list(TS::G3, CAP), *dCHK3 = t->list(TS::CHK3, CAP);
+    float *dB = dBC, *dC = dBC + 2 * (size_t)N;
+    float *dD = dDE, *dE = dD + 2 * (size_t)N, *dCHK = dE + 2 * (size_t)N, *dCHKB = dCHK + 2 * (size_t)N;
     int *dCnt = t->d_out, *dK1 = dCnt + 8, *dK2 = dK1 + N, *dK3 = dK2 + N;
     float *dU1 = (float *)(dK3 + N), *dU2 = dU1 + 2 * (size_t)N, *dU3 = dU2 + 2 * (size_t)N;
     const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4}; // :195-197, :208-209
 
     // The reference makes 8 LK calls per frame.  A point's track depends on nothing but its two images
     // and its start, so the two forward calls inside getOpticalFlow (:205) repeat, on a subset, what
-    // the circular check's first two calls (:457-467) computed: their results are carried through the
-    // gates instead, and the two backward calls (:214) of both getOpticalFlow stages share one launch
-    // over the points that passed the circular check.  Three launches, same values.
+    // the circular check's first two calls (:457-467) computed, and the two backward calls (:214) start
+    // from those same forward tracks: they can be made for every point before the circular check has
+    // chosen, together with the check's own second pair of calls.  Two launches (2 and 4 image pairs over
+    // all N points) and one gate launch, same values; the tracks of points a gate drops are wasted work
+    // on a GPU that a frame's few thousand points leave mostly idle, and the chain of dependent launches
+    // that sets the frame's latency is two tracks long instead of three.
     memcpy(t->h_io, featuresLastLeft.data(), (size_t)N * 8); // the previous frame's read of h_io ended with its sync
     KTLVO_HIP(ctx, hipMemcpyAsync(dA, t->h_io, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
     { // circular check :457-479: LL->LR and LL->CL share their input list
@@ -173,46 +174,23 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         const int po[2] = {0, 0}, no[2] = {0, N};
         rc = launch_pyrlk_ex(ctx, pl, 2, dA, po, dBC, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
         if (rc != KTLVO_OK) return rc;
-        // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft
+    }
+    { // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft (:462-467); and the backward tracks of both
+      // getOpticalFlow stages (:214 as reached from :509 and :513): LR->LL and CL->LL from the same two lists
+        PairList pl;
         pl.prev[0] = (uint16_t)sLR; pl.next[0] = (uint16_t)sCR;
         pl.prev[1] = (uint16_t)sCL; pl.next[1] = (uint16_t)sCR;
-        const int po2[2] = {0, N};
-        rc = launch_pyrlk_ex(ctx, pl, 2, dBC, po2, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
+        pl.prev[2] = (uint16_t)sLR; pl.next[2] = (uint16_t)sLL;
+        pl.prev[3] = (uint16_t)sCL; pl.next[3] = (uint16_t)sLL;
+        const int po[4] = {0, N, 0, N}, no[4] = {0, N, 2 * N, 3 * N};
+        rc = launch_pyrlk_ex(ctx, pl, 4, dBC, po, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
         if (rc != KTLVO_OK) return rc;
     }
-    { // :486-501; the survivors' forward tracks LL->LR and LL->CL come along
-        Gather g;
-        g.src[0] = dA; g.dst[0] = dS1;
-        g.src[1] = dBC; g.dst[1] = dF2;                  // = calcOpticalFlowPyrLK(LastLeft, LastRight, selected) of :509
-        g.src[2] = dBC + 2 * (size_t)N; g.dst[2] = dG2;  // = calcOpticalFlowPyrLK(LastLeft, CurLeft, selected) of :513
-        rc = launch_circular_gate(ctx, dDE, dDE + 2 * (size_t)N, N, dK1, dCnt + 0, g);
-        if (rc != KTLVO_OK) return rc;
-    }
-    { // backward tracks of both getOpticalFlow stages (:214): LR->LL from F2, CL->LL from G2
-        PairList pl;
-        pl.prev[0] = (uint16_t)sLR; pl.next[0] = (uint16_t)sLL;
-        pl.prev[1] = (uint16_t)sCL; pl.next[1] = (uint16_t)sLL;
-        const int po[2] = {0, (int)((dG2 - dF2) / 2)}, no[2] = {0, (int)((dCHKB - dCHK) / 2)};
-        rc = launch_pyrlk_ex(ctx, pl, 2, dF2, po, dCHK, no, ctx->d_status, ctx->d_err, N, dCnt + 0, &lk);
-        if (rc != KTLVO_OK) return rc;
-    }
-    { // gate of getOpticalFlow(LastLeft, LastRight, ..., y_threshold 1), :509
-        Gather g;
-        g.src[0] = dS1; g.dst[0] = dT1;     // featuresLastLeftTemp
-        g.src[1] = dF2; g.dst[1] = dT2;     // featuresLastRightTemp
-        g.src[2] = dG2; g.dst[2] = dG3;     // their forward tracks into CurLeft ...
-        g.src[3] = dCHKB; g.dst[3] = dCHK3; // ... and back
-        rc = launch_fb_gate(ctx, dS1, dF2, dCHK, N, dCnt + 0, 1, dK2, dCnt + 1, g);
-        if (rc != KTLVO_OK) return rc;
-    }
-    { // gate of getOpticalFlow(LastLeft, CurLeft, ..., y_threshold 5, temporal), :513
-        Gather g;
-        g.src[0] = dT1; g.dst[0] = dU1; // featuresLastLeftSelect
-        g.src[1] = dG3; g.dst[1] = dU2; // featuresCurLeftSelect
-        g.src[2] = dT2; g.dst[2] = dU3; // featuresLastRightSelect (features_depth)
-        rc = launch_fb_gate(ctx, dT1, dG3, dCHK3, N, dCnt + 1, 5, dK3, dCnt + 2, g);
-        if (rc != KTLVO_OK) return rc;
-    }
+    // :486-501 circular check, :509 getOpticalFlow(LastLeft, LastRight, y threshold 1), :513 getOpticalFlow(LastLeft,
+    // CurLeft, y threshold 5): kept-index lists of the three and the survivors' featuresLastLeftSelect,
+    // featuresCurLeftSelect, featuresLastRightSelect
+    rc = launch_frame_gates(ctx, dA, dB, dC, dD, dE, dCHK, dCHKB, N, dK1, dK2, dK3, dCnt, dU1, dU2, dU3);
+    if (rc != KTLVO_OK) return rc;
     // One copy and one synchronisation for the whole frame (36 N + 32 bytes into pinned memory).
     KTLVO_HIP(ctx, hipMemcpyAsync(t->h_io, t->d_out, TS::out_ints(N) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
