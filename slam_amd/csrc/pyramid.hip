@@ -55,6 +55,13 @@ __global__ __launch_bounds__(256) void ingest_pad_batch_u8(const SlotDesc *slots
     const LevelDesc L = slots[list.s[blockIdx.z]].lv[0];
     ingest_16(L, src + blockIdx.z * image_stride, stride, ingest_groups(L.w), blockIdx.x * 256 + threadIdx.x);
 }
+// A stereo pair from two separate buffers.  The buffers may lie in pinned host memory: the loads then cross the
+// host link themselves, which for two frames is quicker than two DMA transfers followed by a launch.
+__global__ __launch_bounds__(256) void ingest_pad_pair_u8(const SlotDesc *slots, int slot_a, int slot_b, const uint8_t *src_a,
+                                                          const uint8_t *src_b, int stride) {
+    const LevelDesc L = slots[blockIdx.z ? slot_b : slot_a].lv[0];
+    ingest_16(L, blockIdx.z ? src_b : src_a, stride, ingest_groups(L.w), blockIdx.x * 256 + threadIdx.x);
+}
 static inline unsigned ingest_blocks(int w, int h) { return (unsigned)(((size_t)ingest_groups(w) * (h + 2 * PAD) + 255) / 256); }
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -460,29 +467,35 @@ extern "C" int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, cons
 }
 
 namespace ktlvo {
-// Two frames (a stereo pair) into two slots with one ingest launch, and for pageable sources one DMA: the
-// per-frame path's set-up cost is a handful of runtime calls, and this halves them.  Everything stays on the
-// context's stream (a frame call waits for its own upload anyway, and a second stream would add two events).
+// Two frames (a stereo pair) into two slots with one launch and no DMA: the ingest kernel reads the frames
+// from pinned host memory across the link (the caller's buffers if they are pinned, else a pinned copy made
+// here).  For the 0.9 MB of a KITTI-sized pair the link time is the same either way, and the two DMA
+// set-ups (some 25 us on the frame call's critical path) go away.  Buffers the runtime cannot map for the
+// device take the staged DMA route.
 int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const uint8_t *b, int w, int h) {
     const size_t bytes = (size_t)w * h, img_stride = (bytes + 255) & ~(size_t)255;
     StageRing &r = ctx->stage;
     const bool pinned = is_pinned(a) && is_pinned(b);
     int rc = stage_take(ctx, 2 * img_stride, 0, !pinned);
     if (rc != KTLVO_OK) return rc;
-    uint8_t *d = r.d_batch[0];
-    if (pinned) { // read by DMA where they lie
-        KTLVO_HIP(ctx, hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(d + img_stride, b, bytes, hipMemcpyHostToDevice, ctx->stream));
-    } else {
+    const uint8_t *ha = a, *hb = b;
+    if (!pinned) {
         memcpy(r.h_batch[0], a, bytes);
         memcpy(r.h_batch[0] + img_stride, b, bytes);
-        KTLVO_HIP(ctx, hipMemcpyAsync(d, r.h_batch[0], img_stride + bytes, hipMemcpyHostToDevice, ctx->stream));
+        ha = r.h_batch[0]; hb = r.h_batch[0] + img_stride;
     }
-    SlotList list;
-    list.n = 2;
-    list.s[0] = slot_a; list.s[1] = slot_b;
+    void *da = nullptr, *db = nullptr;
     dim3 grid(ingest_blocks(w, h), 1, 2);
-    hipLaunchKernelGGL(ingest_pad_batch_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, d, img_stride, w);
+    if (hipHostGetDevicePointer(&da, (void *)ha, 0) == hipSuccess && hipHostGetDevicePointer(&db, (void *)hb, 0) == hipSuccess) {
+        hipLaunchKernelGGL(ingest_pad_pair_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot_a, slot_b, (const uint8_t *)da,
+                           (const uint8_t *)db, w);
+    } else {
+        (void)hipGetLastError();
+        uint8_t *d = r.d_batch[0];
+        KTLVO_HIP(ctx, hipMemcpyAsync(d, ha, bytes, hipMemcpyHostToDevice, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(d + img_stride, hb, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(ingest_pad_pair_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot_a, slot_b, d, d + img_stride, w);
+    }
     KTLVO_HIP(ctx, hipGetLastError());
     KTLVO_HIP(ctx, hipEventRecord(r.batch_done[0], ctx->stream));
     r.batch_used[0] = true;
