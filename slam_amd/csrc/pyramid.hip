@@ -165,17 +165,18 @@ __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotLi
 // ---- three levels in one launch ---------------------------------------------------------------------------
 // Levels first+1, first+2, first+3 from level `first`.  The small levels of a pyramid are a few tens of
 // kilobytes each, and a launch per level costs more in launch latency than in work; here a workgroup owns an
-// 8 x 8 tile of the LAST level and forms everything that tile depends on in LDS: an 85 x 85 region of the
-// source level, 41 x 41 of the first new level, 19 x 19 of the second (the halos are recomputed by the
-// neighbouring workgroups).  It writes its exclusive part of each level, 32 x 32, 16 x 16 and 8 x 8 pixels, each
-// with the pixels' reflect-101 copies in the level's frame, as pyr_down_u8 does.
+// TT x TT tile of the LAST level and forms everything that tile depends on in LDS: for TT = 2 a 37 x 37 region
+// of the source level, 17 x 17 of the first new level, 7 x 7 of the second (the halos are recomputed by the
+// neighbouring workgroups; the kernel serves small batches, where more and smaller workgroups finish sooner
+// and the recomputation costs nothing that matters).  It writes its exclusive part of each level, 4 TT, 2 TT
+// and TT pixels square, each with the pixels' reflect-101 copies in the level's frame, as pyr_down_u8 does.
 // pyrDown reflects at the edges of EACH source level, so an intermediate level's entries beyond the level are
 // not computed from mirrored sources (that differs when the level below has an even size) but copied from
 // their mirror images inside the level, which the same region holds.
-constexpr int TT = 8;                 // tile of the last level
-constexpr int R2 = 2 * TT + 3;        // 19: second new level, coordinates 2 x3 - 2 ...
-constexpr int R1 = 2 * R2 + 3;        // 41: first new level, coordinates 4 x3 - 6 ...
-constexpr int R0 = 2 * R1 + 3;        // 85: source level, coordinates 8 x3 - 14 ...
+constexpr int TT = 2;                 // tile of the last level
+constexpr int R2 = 2 * TT + 3;        // second new level, coordinates 2 x3 - 2 ...
+constexpr int R1 = 2 * R2 + 3;        // first new level, coordinates 4 x3 - 6 ...
+constexpr int R0 = 2 * R1 + 3;        // source level, coordinates 8 x3 - 14 ...
 
 // pixel (x, y) of level L and its single reflections into the frame (pyr_store_row's rule, per pixel)
 __device__ __forceinline__ void store_mirrored(const LevelDesc &L, int x, int y, uint8_t v) {
@@ -242,17 +243,17 @@ __global__ __launch_bounds__(256) void pyr_down_tail3(const SlotDesc *slots, Slo
     lds_pyr_step<R0, R1>(s0, s1, tmp, 4 * x3 - 6, 4 * y3 - 6, L1.w, L1.h);
     lds_pyr_step<R1, R2>(s1, s2, tmp, 2 * x3 - 2, 2 * y3 - 2, L2.w, L2.h);
     lds_pyr_step<R2, TT>(s2, s3, tmp, x3, y3, L3.w, L3.h);
-    // exclusive parts: 32 x 32 of L1 at (4 x3, 4 y3), entry (6, 6) of s1; 16 x 16 of L2 at (2 x3, 2 y3), entry (2, 2) of s2
-    for (int i = tid; i < 32 * 32; i += 256) {
-        const int r = i >> 5, c = i & 31, x = 4 * x3 + c, y = 4 * y3 + r;
+    // exclusive parts: 4 TT x 4 TT of L1 at (4 x3, 4 y3), entry (6, 6) of s1; 2 TT x 2 TT of L2 at (2 x3, 2 y3), entry (2, 2) of s2
+    for (int i = tid; i < 16 * TT * TT; i += 256) {
+        const int r = i / (4 * TT), c = i - r * (4 * TT), x = 4 * x3 + c, y = 4 * y3 + r;
         if (x < L1.w && y < L1.h) store_mirrored(L1, x, y, s1[r + 6][c + 6]);
     }
-    {
-        const int r = tid >> 4, c = tid & 15, x = 2 * x3 + c, y = 2 * y3 + r;
+    for (int i = tid; i < 4 * TT * TT; i += 256) {
+        const int r = i / (2 * TT), c = i - r * (2 * TT), x = 2 * x3 + c, y = 2 * y3 + r;
         if (x < L2.w && y < L2.h) store_mirrored(L2, x, y, s2[r + 2][c + 2]);
     }
-    if (tid < TT * TT) {
-        const int r = tid >> 3, c = tid & 7, x = x3 + c, y = y3 + r;
+    for (int i = tid; i < TT * TT; i += 256) {
+        const int r = i / TT, c = i - r * TT, x = x3 + c, y = y3 + r;
         if (x < L3.w && y < L3.h) store_mirrored(L3, x, y, s3[r][c]);
     }
 }
@@ -529,8 +530,8 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
             ProfScope ps(ctx, KTLVO_K_PYRDOWN);
             // level 0 -> 1 streams; with the reference's five levels and a handful of images (the per-frame path
             // builds two), levels 2, 3 and 4 then come from ONE launch: three launches of a few workgroups each
-            // cost 25 us in launch latency there, the fused kernel 8.  For large batches the per-level launches are
-            // faster (the fused kernel recomputes halos through LDS: 0.14 against 0.09 ms for 256 images).
+            // cost 25 us in launch latency there, the fused kernel 9.  For large batches the per-level launches are
+            // faster (the fused kernel recomputes halos through LDS, several times over with its small tiles).
             // (KTLVO_PYR_PER_LEVEL=1 in the environment at context creation keeps a launch per level: A/B and tests)
             const bool tail = top == 4 && list.n <= 8 && !ctx->pyr_per_level;
             for (int l = 0; l < (tail ? 1 : top); l++) {
