@@ -97,6 +97,7 @@ struct ktlvo_ctx {
     int *d_idx = nullptr;   // max_points + 1 ints
     void *d_misc = nullptr; // corner / ransac work area
     size_t misc_bytes = 0;
+    bool frame_chain = true;    // the frame path's six tracks from one launch (KTLVO_FRAME_PER_STAGE=1 at creation: a launch per stage)
     bool pyr_per_level = false; // one pyrDown launch per level instead of the fused small-level kernel (A/B, tests)
     void *noalloc_scratch = nullptr; // this device's address of the fixed scratch array of ktlvo_detect_gftt_noalloc
     void *d_aux = nullptr;  // sort buffer and cell grid of whole-frame corner selection
@@ -150,5 +151,9 @@ int launch_pyrlk(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float
 int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, const int *prev_off,
                     float *d_next, const int *next_off, uint8_t *d_status, float *d_err, int n_per_pair,
                     const int *d_n, const ktlvo_lk_params *p);
+
+// The six tracks of a stereo frame from one launch (pyrlk.hip); d_out = B, C, D, E, CHK, CHKB.
+int launch_frame_chain(ktlvo_ctx *ctx, int sLL, int sLR, int sCL, int sCR, const float *dA, int n, float *const d_out[6],
+                       const ktlvo_lk_params *p);
 
 } // namespace ktlvo

@@ -22,6 +22,15 @@
 
 namespace ktlvo {
 
+// Termination and acceptance criteria of a track, as the launcher prepares them; every kernel argument struct
+// carries these fields under these names (lk_track reads them from whichever struct it is given).
+#define KTLVO_LK_CRITERIA                                                                                       \
+    int max_level;                                                                                              \
+    int max_count;                                                                                              \
+    double eps_sq;                                                                                              \
+    float eps_lo, eps_hi; /* float step^2 at or below eps_lo passes, at or above eps_hi fails, without doubles */ \
+    double min_eig_thr;                                                                                         \
+    float min_eig_lo, min_eig_hi; /* float minEig estimates outside [lo, hi] decide without the exact value */
 struct LkArgs {
     const SlotDesc *slots;
     const float *prev;
@@ -31,12 +40,7 @@ struct LkArgs {
     int n_per_pair;
     int n_pairs;
     int blocks_per_pair; // ceil(n_per_pair / LK_WPB)
-    int max_level;
-    int max_count;
-    double eps_sq;
-    float eps_lo, eps_hi; // float step^2 at or below eps_lo passes, at or above eps_hi fails, without doubles
-    double min_eig_thr;
-    float min_eig_lo, min_eig_hi; // float minEig estimates outside [lo, hi] decide without the exact value
+    KTLVO_LK_CRITERIA
     const int *d_n; // optional: actual point count lives in device memory (<= n_per_pair)
     PairList pairs;
     int prev_off[MAX_BATCH]; // first point of pair i in prev[]
@@ -394,38 +398,18 @@ __device__ __forceinline__ void scalar_xy(int vx, int vy, int &sx, int &sy) {
 #ifndef LK_WPB
 #define LK_WPB 1
 #endif
+// One feature's track through all levels, by one wavefront: prev point (ppx, ppy) in the image of slot SP, result
+// (ox, oy), status and error as calcOpticalFlowPyrLK returns them for that point.  All arguments and results are
+// wave-uniform.
 // MAXL >= 0 fixes the top level at compile time, and the level loop is then unrolled (level-dependent scalars
-// become constants; 0.5 % faster at five times the code); MAXL < 0 takes it from the arguments.
-template <int MAXL>
-__global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void pyrlk_track_w21(LkArgs a) {
-    const int max_level = MAXL >= 0 ? MAXL : a.max_level;
-    const int lane = threadIdx.x & 63;
-    const int wave = uniform((int)(threadIdx.x >> 6));
-    // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each with its
-    // own 4 MiB L2.  Pairs are taken in groups of 8: all workgroups of a group's pair i get block ids
-    // of residue class i mod 8, so a pair's two pyramids are fetched into one L2 instead of eight.
-    // The pairs left over after the last full group are spread over all XCDs, so none runs dry
-    // early.  This is a locality hint only; any placement gives the same results.
-    const int grouped = (a.n_pairs >> 3) * 8 * a.blocks_per_pair; // blocks of the full groups
-    int pair, blk;
-    if ((int)blockIdx.x < grouped) {
-        const int q = blockIdx.x >> 3;
-        pair = (blockIdx.x & 7) + 8 * (q / a.blocks_per_pair);
-        blk = q % a.blocks_per_pair;
-    } else {
-        const int q = blockIdx.x - grouped;
-        pair = (a.n_pairs & ~7) + q / a.blocks_per_pair;
-        blk = q % a.blocks_per_pair;
-    }
-    const int f = blk * LK_WPB + wave;
-    const int n = a.d_n ? min(*a.d_n, a.n_per_pair) : a.n_per_pair;
-    if (f >= n) return;
-    const SlotDesc &SP = a.slots[a.pairs.prev[pair]];
-    const SlotDesc &SN = a.slots[a.pairs.next[pair]];
-    const size_t gp = (size_t)a.prev_off[pair] + f;
-    const size_t gi = (size_t)a.next_off[pair] + f;
-    const float ppx = a.prev[2 * gp], ppy = a.prev[2 * gp + 1];
-
+// become constants; 0.5 % faster at five times the code); MAXL < 0 takes it from the criteria.
+struct LkResult {
+    float x, y, err;
+    int status;
+};
+template <int MAXL, class Args>
+__device__ __forceinline__ LkResult lk_track(const Args &cr, const int max_level, const SlotDesc &SP, const SlotDesc &SN,
+                                             const float ppx, const float ppy, const int lane) {
     const bool active = lane < 63;
     // Row-major: the three lanes of a window row are neighbours, so the four lanes the memory pipeline
     // takes together touch two cache lines instead of four (1.8 % faster than run-major on the same box).
@@ -534,9 +518,9 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         const float quick = (tr - __builtin_amdgcn_sqrtf(disc)) * (1.f / (float)(2 * WIN * WIN));
         const float slack = tr * (1.f / (262144.f * (float)(2 * WIN * WIN)));
         bool weak;
-        if (quick > a.min_eig_hi + slack) weak = false;
-        else if (quick < a.min_eig_lo - slack) weak = true;
-        else weak = (double)((tr - sqrtf(disc)) / (float)(2 * WIN * WIN)) < a.min_eig_thr;
+        if (quick > cr.min_eig_hi + slack) weak = false;
+        else if (quick < cr.min_eig_lo - slack) weak = true;
+        else weak = (double)((tr - sqrtf(disc)) / (float)(2 * WIN * WIN)) < cr.min_eig_thr;
         if (weak || D < 1.1920928955078125e-07f) {
             if (level == 0) status = 0;
             continue;
@@ -583,8 +567,8 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             // dx*dx + dy*dy <= eps^2 is decided in double, as OpenCV's arithmetic promotes it; the
             // float sum is within 2^-22 of it, so only values next to the threshold need the doubles
             const float step_sq = dx * dx + dy * dy;
-            if (step_sq < a.eps_hi) {
-                if (step_sq <= a.eps_lo || (double)dx * dx + (double)dy * dy <= a.eps_sq) return 1;
+            if (step_sq < cr.eps_hi) {
+                if (step_sq <= cr.eps_lo || (double)dx * dx + (double)dy * dy <= cr.eps_sq) return 1;
             }
             // OpenCV compares |.| with the double 0.01; float(0.01) is the largest float below it,
             // so "<= 0.01f" is the same predicate without leaving single precision
@@ -596,7 +580,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
                 backx = dx * 0.5f; backy = dy * 0.5f;
                 return 1;
             }
-            if (++j >= a.max_count) return 1;
+            if (++j >= cr.max_count) return 1;
             frac = f32x2{nx, ny} - f32x2{flx, fly};
             if (__float_as_uint(frac.x) < 0x3F800000u && __float_as_uint(frac.y) < 0x3F800000u) return 0;
             flx = floorf(nx); fly = floorf(ny);
@@ -613,7 +597,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
         // loop is unrolled twice with the two register pairs changing roles, so that no step copies
         // its result into "previous".
         float p0x, p0y, p1x = 1e30f, p1y = 1e30f;
-        if (a.max_count > 0) {
+        if (cr.max_count > 0) {
             for (;;) {
                 if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
                     if (level == 0) status = 0;
@@ -669,12 +653,138 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
             }
         }
     }
-    if (lane == 0) {
-        a.next[2 * gi] = ox;
-        a.next[2 * gi + 1] = oy;
-        a.status[gi] = (uint8_t)status;
-        a.err[gi] = errv;
+    LkResult res;
+    res.x = ox; res.y = oy; res.err = errv; res.status = status;
+    return res;
+}
+
+template <int MAXL>
+__global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void pyrlk_track_w21(LkArgs a) {
+    const int max_level = MAXL >= 0 ? MAXL : a.max_level;
+    const int lane = threadIdx.x & 63;
+    const int wave = uniform((int)(threadIdx.x >> 6));
+    // Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), each with its
+    // own 4 MiB L2.  Pairs are taken in groups of 8: all workgroups of a group's pair i get block ids
+    // of residue class i mod 8, so a pair's two pyramids are fetched into one L2 instead of eight.
+    // The pairs left over after the last full group are spread over all XCDs, so none runs dry
+    // early.  This is a locality hint only; any placement gives the same results.
+    const int grouped = (a.n_pairs >> 3) * 8 * a.blocks_per_pair; // blocks of the full groups
+    int pair, blk;
+    if ((int)blockIdx.x < grouped) {
+        const int q = blockIdx.x >> 3;
+        pair = (blockIdx.x & 7) + 8 * (q / a.blocks_per_pair);
+        blk = q % a.blocks_per_pair;
+    } else {
+        const int q = blockIdx.x - grouped;
+        pair = (a.n_pairs & ~7) + q / a.blocks_per_pair;
+        blk = q % a.blocks_per_pair;
     }
+    const int f = blk * LK_WPB + wave;
+    const int n = a.d_n ? min(*a.d_n, a.n_per_pair) : a.n_per_pair;
+    if (f >= n) return;
+    const SlotDesc &SP = a.slots[a.pairs.prev[pair]];
+    const SlotDesc &SN = a.slots[a.pairs.next[pair]];
+    const size_t gp = (size_t)a.prev_off[pair] + f;
+    const size_t gi = (size_t)a.next_off[pair] + f;
+    const float ppx = a.prev[2 * gp], ppy = a.prev[2 * gp + 1];
+
+    const LkResult res = lk_track<MAXL>(a, max_level, SP, SN, ppx, ppy, lane);
+    if (lane == 0) {
+        a.next[2 * gi] = res.x;
+        a.next[2 * gi + 1] = res.y;
+        a.status[gi] = (uint8_t)res.status;
+        a.err[gi] = res.err;
+    }
+}
+
+// The six tracks of a stereo frame (featureTracking.cpp:457-467 and the four calls inside the two getOpticalFlow
+// stages, :205-214 as reached from :509 and :513) from ONE launch.  A point's tracks form two chains that
+// share nothing: last left -> last right -> {current right, back to last left}, and last left -> current left ->
+// {current right, back to last left}.  A workgroup of four waves takes one start point; wave `role` makes the
+// first track of its chain and then its own second track, so no wave ever waits for another (the first track
+// of each chain is made twice, which costs nothing on a GPU that a frame's points leave mostly idle):
+//   role 0: LL->LR (writes B), LR->CR (writes D)      role 1: LL->CL (writes C), CL->CR (writes E)
+//   role 2: LL->LR,            LR->LL (writes CHK)    role 3: LL->CL,            CL->LL (writes CHKB)
+// Compared with a launch per stage, the frame waits for its slowest chain instead of the slowest track of each
+// stage in turn.  Values are those of pyrlk_track_w21 (same lk_track); status and error are not needed by the
+// frame's gates and are not stored.
+struct ChainArgs {
+    const SlotDesc *slots;
+    const float *A;
+    float *out[6]; // B, C, D, E, CHK, CHKB
+    int n;
+    int sLL, sLR, sCL, sCR;
+    KTLVO_LK_CRITERIA
+};
+template <int MAXL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pyrlk_frame_chain(ChainArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int role = uniform((int)(threadIdx.x >> 6));
+    const int f = blockIdx.x;
+    if (f >= a.n) return;
+    const bool stereo = !(role & 1);
+    const int mid = stereo ? a.sLR : a.sCL;
+    const int last = (role & 2) ? a.sLL : a.sCR;
+    float x = a.A[2 * f], y = a.A[2 * f + 1];
+    for (int t = 0; t < 2; t++) {
+        const SlotDesc &SP = a.slots[t ? mid : a.sLL];
+        const SlotDesc &SN = a.slots[t ? last : mid];
+        const LkResult res = lk_track<MAXL>(a, MAXL, SP, SN, x, y, lane);
+        x = res.x; y = res.y;
+        float *dst = t ? a.out[2 + role] : (role < 2 ? a.out[role] : nullptr);
+        if (lane == 0 && dst) { dst[2 * f] = x; dst[2 * f + 1] = y; }
+    }
+}
+
+// Fills the criteria fields of a kernel argument struct from the caller's parameters, as OpenCV clamps them.
+template <class Args>
+static void set_criteria(Args &a, const ktlvo_lk_params *p, int max_level) {
+    a.max_level = max_level;
+    int mc = p->max_count; // OpenCV clamps TermCriteria the same way
+    a.max_count = mc < 0 ? 0 : mc > 100 ? 100 : mc;
+    double eps = p->epsilon < 0 ? 0 : p->epsilon > 10 ? 10 : p->epsilon;
+    a.eps_sq = eps * eps;
+    if (a.eps_sq >= 1e-30) {
+        a.eps_lo = (float)(a.eps_sq * (1.0 - 1e-6));
+        a.eps_hi = (float)(a.eps_sq * (1.0 + 1e-6));
+    } else { // float squares may underflow here: always decide in double
+        a.eps_lo = -1.f;
+        a.eps_hi = __builtin_inff();
+    }
+    a.min_eig_thr = p->min_eig_thr;
+    if (p->min_eig_thr >= 1e-12 && p->min_eig_thr <= 1e12) {
+        a.min_eig_lo = (float)(p->min_eig_thr * (1.0 - 1e-5));
+        a.min_eig_hi = (float)(p->min_eig_thr * (1.0 + 1e-5));
+    } else { // unusual thresholds (zero, negative, huge, NaN): always take the exact value
+        a.min_eig_lo = -__builtin_inff();
+        a.min_eig_hi = __builtin_inff();
+    }
+}
+
+// d_out: B, C, D, E, CHK, CHKB as in pyrlk_frame_chain, n points each.  Returns KTLVO_ERR_UNSUPPORTED when the four
+// slots do not all hold the reference's five levels (the caller then takes the launch-per-stage route).
+int launch_frame_chain(ktlvo_ctx *ctx, int sLL, int sLR, int sCL, int sCR, const float *dA, int n, float *const d_out[6],
+                       const ktlvo_lk_params *p) {
+    if (!p || p->win != WIN) return KTLVO_ERR_UNSUPPORTED;
+    const int s[4] = {sLL, sLR, sCL, sCR};
+    for (int i = 0; i < 4; i++) {
+        if (!slot_ok(ctx, s[i])) return KTLVO_ERR_INVALID;
+        if (ctx->built[s[i]] < 0) return KTLVO_ERR_STATE;
+        if (ctx->built[s[i]] < p->max_level || p->max_level != 4) return KTLVO_ERR_UNSUPPORTED;
+    }
+    if (!ctx->deriv_ok[sLL] || !ctx->deriv_ok[sLR] || !ctx->deriv_ok[sCL]) return KTLVO_ERR_STATE; // the template images
+    if (n <= 0) return n == 0 ? KTLVO_OK : KTLVO_ERR_INVALID;
+    ChainArgs a;
+    a.slots = ctx->d_slots;
+    a.A = dA;
+    for (int i = 0; i < 6; i++) a.out[i] = d_out[i];
+    a.n = n;
+    a.sLL = sLL; a.sLR = sLR; a.sCL = sCL; a.sCR = sCR;
+    set_criteria(a, p, 4);
+    ProfScope ps(ctx, KTLVO_K_PYRLK);
+    hipLaunchKernelGGL(pyrlk_frame_chain<4>, dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
 }
 
 int launch_pyrlk(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const float *d_prev, int n_per_pair,
@@ -706,26 +816,7 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     a.slots = ctx->d_slots;
     a.prev = d_prev; a.next = d_next; a.status = d_status; a.err = d_err;
     a.n_per_pair = n_per_pair;
-    a.max_level = max_level;
-    int mc = p->max_count; // OpenCV clamps TermCriteria the same way
-    a.max_count = mc < 0 ? 0 : mc > 100 ? 100 : mc;
-    double eps = p->epsilon < 0 ? 0 : p->epsilon > 10 ? 10 : p->epsilon;
-    a.eps_sq = eps * eps;
-    if (a.eps_sq >= 1e-30) {
-        a.eps_lo = (float)(a.eps_sq * (1.0 - 1e-6));
-        a.eps_hi = (float)(a.eps_sq * (1.0 + 1e-6));
-    } else { // float squares may underflow here: always decide in double
-        a.eps_lo = -1.f;
-        a.eps_hi = __builtin_inff();
-    }
-    a.min_eig_thr = p->min_eig_thr;
-    if (p->min_eig_thr >= 1e-12 && p->min_eig_thr <= 1e12) {
-        a.min_eig_lo = (float)(p->min_eig_thr * (1.0 - 1e-5));
-        a.min_eig_hi = (float)(p->min_eig_thr * (1.0 + 1e-5));
-    } else { // unusual thresholds (zero, negative, huge, NaN): always take the exact value
-        a.min_eig_lo = -__builtin_inff();
-        a.min_eig_hi = __builtin_inff();
-    }
+    set_criteria(a, p, max_level);
     a.d_n = d_n;
     a.pairs = pairs;
     for (int i = 0; i < n_pairs; i++) { a.prev_off[i] = prev_off[i]; a.next_off[i] = next_off[i]; }
@@ -735,6 +826,7 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     ProfScope ps(ctx, KTLVO_K_PYRLK);
     // the reference's maxLevel (featureTracking.cpp:208) gets the unrolled kernel
     if (max_level == 4) hipLaunchKernelGGL(pyrlk_track_w21<4>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
+    else if (max_level == 3) hipLaunchKernelGGL(pyrlk_track_w21<3>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
     else hipLaunchKernelGGL(pyrlk_track_w21<-1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;

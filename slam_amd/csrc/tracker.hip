@@ -167,25 +167,32 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     // that sets the frame's latency is two tracks long instead of three.
     memcpy(t->h_io, featuresLastLeft.data(), (size_t)N * 8); // the previous frame's read of h_io ended with its sync
     KTLVO_HIP(ctx, hipMemcpyAsync(dA, t->h_io, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
-    { // circular check :457-479: LL->LR and LL->CL share their input list
-        PairList pl;
-        pl.prev[0] = (uint16_t)sLL; pl.next[0] = (uint16_t)sLR;
-        pl.prev[1] = (uint16_t)sLL; pl.next[1] = (uint16_t)sCL;
-        const int po[2] = {0, 0}, no[2] = {0, N};
-        rc = launch_pyrlk_ex(ctx, pl, 2, dA, po, dBC, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
-        if (rc != KTLVO_OK) return rc;
+    // With the reference's five pyramid levels all six tracks come from one launch (pyrlk_frame_chain: a wave per
+    // chain of two tracks, so the frame waits for its slowest chain rather than for the slowest track of each stage
+    // in turn); otherwise from a launch per stage.
+    float *const chain_out[6] = {dB, dC, dD, dE, dCHK, dCHKB};
+    rc = ctx->frame_chain ? launch_frame_chain(ctx, sLL, sLR, sCL, sCR, dA, N, chain_out, &lk) : KTLVO_ERR_UNSUPPORTED;
+    if (rc == KTLVO_ERR_UNSUPPORTED) {
+        { // circular check :457-479: LL->LR and LL->CL share their input list
+            PairList pl;
+            pl.prev[0] = (uint16_t)sLL; pl.next[0] = (uint16_t)sLR;
+            pl.prev[1] = (uint16_t)sLL; pl.next[1] = (uint16_t)sCL;
+            const int po[2] = {0, 0}, no[2] = {0, N};
+            rc = launch_pyrlk_ex(ctx, pl, 2, dA, po, dBC, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
+            if (rc != KTLVO_OK) return rc;
+        }
+        { // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft (:462-467); and the backward tracks of both
+          // getOpticalFlow stages (:214 as reached from :509 and :513): LR->LL and CL->LL from the same two lists
+            PairList pl;
+            pl.prev[0] = (uint16_t)sLR; pl.next[0] = (uint16_t)sCR;
+            pl.prev[1] = (uint16_t)sCL; pl.next[1] = (uint16_t)sCR;
+            pl.prev[2] = (uint16_t)sLR; pl.next[2] = (uint16_t)sLL;
+            pl.prev[3] = (uint16_t)sCL; pl.next[3] = (uint16_t)sLL;
+            const int po[4] = {0, N, 0, N}, no[4] = {0, N, 2 * N, 3 * N};
+            rc = launch_pyrlk_ex(ctx, pl, 4, dBC, po, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
+        }
     }
-    { // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft (:462-467); and the backward tracks of both
-      // getOpticalFlow stages (:214 as reached from :509 and :513): LR->LL and CL->LL from the same two lists
-        PairList pl;
-        pl.prev[0] = (uint16_t)sLR; pl.next[0] = (uint16_t)sCR;
-        pl.prev[1] = (uint16_t)sCL; pl.next[1] = (uint16_t)sCR;
-        pl.prev[2] = (uint16_t)sLR; pl.next[2] = (uint16_t)sLL;
-        pl.prev[3] = (uint16_t)sCL; pl.next[3] = (uint16_t)sLL;
-        const int po[4] = {0, N, 0, N}, no[4] = {0, N, 2 * N, 3 * N};
-        rc = launch_pyrlk_ex(ctx, pl, 4, dBC, po, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
-        if (rc != KTLVO_OK) return rc;
-    }
+    if (rc != KTLVO_OK) return rc;
     // :486-501 circular check, :509 getOpticalFlow(LastLeft, LastRight, y threshold 1), :513 getOpticalFlow(LastLeft,
     // CurLeft, y threshold 5): kept-index lists of the three and the survivors' featuresLastLeftSelect,
     // featuresCurLeftSelect, featuresLastRightSelect
