@@ -179,6 +179,32 @@ def test_pinned_frames_may_be_reused_after_every_call(make_ctx):
     assert len(ref[0]) > 100
 
 
+def test_frame_chain_launch_equals_launch_per_stage(make_ctx):
+    """The six tracks of a frame from one launch (pyrlk_frame_chain) against a launch per stage
+    (KTLVO_FRAME_PER_STAGE=1 at context creation), and a four-level pyramid, where the one-launch form does not
+    apply and the frame call takes the per-stage route by itself: identical clouds, frame after frame."""
+    import os
+    W, H = 1242, 375
+    scene = synth.CorridorScene(W, H, seed=0x5EED0007)
+    os.environ["KTLVO_FRAME_PER_STAGE"] = "1"
+    try:
+        per_stage = make_ctx()
+    finally:
+        del os.environ["KTLVO_FRAME_PER_STAGE"]
+    chain = make_ctx()
+    n_pts = 0
+    for f in range(6):
+        L, R = scene.stereo_pair(f)
+        ref, got = per_stage.track_stereo_frame(L, R), chain.track_stereo_frame(L, R)
+        assert got[0].tobytes() == ref[0].tobytes() and got[1].tobytes() == ref[1].tobytes() and got[2] == ref[2]
+        n_pts += len(ref[0])
+    assert n_pts > 1500
+    small = make_ctx(max_level=3)      # four levels: no one-launch form, same call
+    for f in range(3):
+        last, cur, kf = small.track_stereo_frame(*scene.stereo_pair(f))
+    assert len(last) > 100
+
+
 def test_tracker_output_capacity(make_ctx, klib):
     """Arrays too small for a frame's points: the call says so, fills what fits, and the tracker's own
     state stays whole (the next frame goes on as if nothing had happened)."""
