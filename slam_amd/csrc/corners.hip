@@ -74,7 +74,7 @@ __global__ void corner_setup(RoiTable t, int n_roi, RoiDev *rois, unsigned *roi_
 __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, int slot, const RoiDev *rois, float s1,
                                                          float s2, int harris, double k, float *resp_out,
                                                          unsigned *roi_max, unsigned long long *cand, int *cand_cnt,
-                                                         int3 tiles) {
+                                                         int3 tiles, const int *roi_slots) {
     // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Consecutive ids therefore take
     // tiles that lie an eighth of the launch apart, and the workgroups of one XCD walk a contiguous run of
     // tiles in raster order: neighbouring tiles, which share image lines (32-pixel tiles, 128-byte lines) and
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
     const RoiDev R = rois[roi_id];
     const int tx0 = (tr % tiles_x) * CT, ty0 = (tr / tiles_x) * CT;
     if (tx0 >= R.w || ty0 >= R.h) return;
-    const LevelDesc L = slots[slot].lv[0];
+    const LevelDesc L = slots[roi_slots ? roi_slots[roi_id] : slot].lv[0]; // a batch of frames: every ROI names its slot
     __shared__ uint8_t img[CI][CI + 2];
     __shared__ float cxx[CC][CC + 1], cxy[CC][CC + 1], cyy[CC][CC + 1];
     __shared__ float rsp[CR][CR + 1];
@@ -331,9 +331,13 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
 // ---- large ROIs (whole frames) ---------------------------------------------------------------------------
 // Keys of one ROI whose value exceeds the ROI's threshold, compacted (in any order) into out[]; the
 // remainder of out[] up to out_cap is cleared so that a power-of-two sort can run over it.
+// blockIdx.y selects one of several ROIs handled by the launch (a batch of frames): ROI f's candidates start
+// cand_stride keys after ROI f-1's, its output out_stride keys, its counters and maximum one element.
 __global__ __launch_bounds__(256) void cand_filter(const unsigned long long *cand, const int *cand_cnt,
                                                    const unsigned *roi_max, double quality, unsigned long long *out,
-                                                   int *out_cnt) {
+                                                   int *out_cnt, size_t cand_stride, size_t out_stride) {
+    cand += blockIdx.y * cand_stride; out += blockIdx.y * out_stride;
+    cand_cnt += blockIdx.y; roi_max += blockIdx.y; out_cnt += blockIdx.y;
     const int n = *cand_cnt;
     const float thr = roi_threshold(*roi_max, quality);
     __shared__ int wave_off[4];
@@ -378,7 +382,9 @@ __device__ __forceinline__ void bitonic_lds_steps(unsigned long long *s, int n_l
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *keys, int np2) {
+// (blockIdx.y selects one of several lists sorted by the same launch, list_stride keys apart)
+__global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *keys, int np2, size_t list_stride) {
+    keys += blockIdx.y * list_stride;
     __shared__ unsigned long long s[BL];
     const int n_local = np2 < BL ? np2 : BL;
     const size_t gbase = (size_t)blockIdx.x * BL;
@@ -387,7 +393,8 @@ __global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *k
     for (int k = 2; k <= n_local; k <<= 1) bitonic_lds_steps(s, n_local, gbase, (size_t)k, k >> 1);
     for (int i = threadIdx.x; i < n_local; i += blockDim.x) keys[gbase + i] = s[i];
 }
-__global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *keys, unsigned k) {
+__global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *keys, unsigned k, size_t list_stride) {
+    keys += blockIdx.y * list_stride;
     __shared__ unsigned long long s[BL];
     const size_t gbase = (size_t)blockIdx.x * BL;
     for (int i = threadIdx.x; i < BL; i += blockDim.x) s[i] = keys[gbase + i];
@@ -395,7 +402,8 @@ __global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *
     bitonic_lds_steps(s, BL, gbase, (size_t)k, BL >> 1);
     for (int i = threadIdx.x; i < BL; i += blockDim.x) keys[gbase + i] = s[i];
 }
-__global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *keys, unsigned j, unsigned k) {
+__global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *keys, unsigned j, unsigned k, size_t list_stride) {
+    keys += blockIdx.y * list_stride;
     // thread t owns the pair (i, i | j) with i = t with a zero bit inserted at position log2(j)
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t i = ((t & ~((size_t)j - 1)) << 1) | (t & ((size_t)j - 1));
@@ -417,6 +425,8 @@ struct SelLargeArgs {
     float *xy, *resp;
     int *count;
     int *overflow;
+    // a batch of ROIs of one size (blockIdx.x = ROI f): f's keys, cells and outputs lie these many elements after f-1's
+    size_t keys_stride, cells_stride, out_stride;
 };
 constexpr int CH = 512;  // candidates per chunk of the greedy pass
 constexpr int HT = 2048; // chunk-local hash of the survivors' cells (load factor <= 1/4)
@@ -433,6 +443,9 @@ constexpr int HT = 2048; // chunk-local hash of the survivors' cells (load facto
 // chains are short because a chunk's candidates are scattered over the frame; (4) the accepted ones take
 // their output places in rank order and enter the grid.
 __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
+    a.keys += blockIdx.x * a.keys_stride; a.n_ptr += blockIdx.x; a.count += blockIdx.x;
+    a.cell_cnt += blockIdx.x * a.cells_stride; a.cell_pts += blockIdx.x * a.cells_stride;
+    a.xy += blockIdx.x * a.out_stride * 2; a.resp += blockIdx.x * a.out_stride;
     __shared__ unsigned long long s_key[CH];
     __shared__ int s_x[CH], s_y[CH];
     __shared__ unsigned conf[CH][CH / 32];
@@ -577,7 +590,9 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
 
 // first `limit` keys of a sorted list, no distance test (min_dist < 1)
 __global__ void corner_take_first(const unsigned long long *keys, const int *n_ptr, int w, int limit, float *xy,
-                                  float *resp, int *count) {
+                                  float *resp, int *count, size_t keys_stride, size_t out_stride) {
+    keys += blockIdx.y * keys_stride; n_ptr += blockIdx.y; count += blockIdx.y; // blockIdx.y = ROI of a batch
+    xy += blockIdx.y * out_stride * 2; resp += blockIdx.y * out_stride;
     const int n = min(*n_ptr, limit);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -660,13 +675,13 @@ static int corner_scratch_setup(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, c
 }
 
 static int run_candidates(ktlvo_ctx *ctx, int slot, int n_roi, int maxw, int maxh, int use_harris, double k,
-                          const CornerScratch &s, float *d_resp_out, bool want_candidates) {
+                          const CornerScratch &s, float *d_resp_out, bool want_candidates, const int *d_roi_slots = nullptr) {
     const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0); // cornerEigenValsVecs: 2^(ksize-1) * blockSize * 255
     const float s1 = (float)(1.0 * scale), s2 = (float)(2.0 * scale);
     const int3 tiles = {(maxw + CT - 1) / CT, (maxh + CT - 1) / CT, n_roi};
     const int n_tiles = tiles.x * tiles.y * tiles.z;
     hipLaunchKernelGGL(corner_candidates, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois,
-                       s1, s2, use_harris, k, d_resp_out, s.d_max, want_candidates ? s.d_cand : nullptr, s.d_cnt, tiles);
+                       s1, s2, use_harris, k, d_resp_out, s.d_max, want_candidates ? s.d_cand : nullptr, s.d_cnt, tiles, d_roi_slots);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }
@@ -703,6 +718,20 @@ static int ensure_aux(ktlvo_ctx *ctx, size_t bytes) {
     return KTLVO_OK;
 }
 
+// n_lists lists of np2 keys each (np2 a power of two), back to back, each sorted descending.
+static int sort_keys(ktlvo_ctx *ctx, unsigned long long *d_keys, size_t np2, int n_lists) {
+    const unsigned L = (unsigned)n_lists;
+    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL), L), dim3(1024), 0, ctx->stream, d_keys, (int)np2, np2);
+    for (size_t k = 2 * (size_t)BL; k <= np2; k <<= 1) {
+        for (size_t j = k >> 1; j >= (size_t)BL; j >>= 1)
+            hipLaunchKernelGGL(bitonic_global_step, dim3((unsigned)(np2 / 512), L), dim3(256), 0, ctx->stream, d_keys, (unsigned)j,
+                               (unsigned)k, np2);
+        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL), L), dim3(1024), 0, ctx->stream, d_keys, (unsigned)k, np2);
+    }
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
 // Sort + greedy pass of one large ROI on the device.  n_sup = the ROI's candidate count (already on the host).
 static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, const ktlvo_gftt_params *p,
                         const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap) {
@@ -729,29 +758,123 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     if (dist) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)gw * gh * 16, ctx->stream));
     const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
     hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
-                       p->quality, d_keys, d_n);
+                       p->quality, d_keys, d_n, (size_t)0, (size_t)0);
     KTLVO_HIP(ctx, hipGetLastError());
     // How many passed is only known on the device; the sort is sized for the candidate count, which bounds it.
-    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL)), dim3(1024), 0, ctx->stream, d_keys, (int)np2);
-    for (size_t k = 2 * (size_t)BL; k <= np2; k <<= 1) {
-        for (size_t j = k >> 1; j >= (size_t)BL; j >>= 1)
-            hipLaunchKernelGGL(bitonic_global_step, dim3((unsigned)(np2 / 512)), dim3(256), 0, ctx->stream, d_keys, (unsigned)j,
-                               (unsigned)k);
-        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL)), dim3(1024), 0, ctx->stream, d_keys, (unsigned)k);
-    }
-    KTLVO_HIP(ctx, hipGetLastError());
+    rc = sort_keys(ctx, d_keys, np2, 1);
+    if (rc != KTLVO_OK) return rc;
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     if (!dist) {
         hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256), dim3(256), 0, ctx->stream, d_keys, d_n, R.w, limit, d_xy,
-                           d_resp, d_count);
+                           d_resp, d_count, (size_t)0, (size_t)0);
     } else {
         SelLargeArgs a;
         a.keys = d_keys; a.n_ptr = d_n; a.w = R.w; a.h = R.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh;
         a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
         a.xy = d_xy; a.resp = d_resp; a.count = d_count; a.overflow = s.d_overflow;
+        a.keys_stride = a.cells_stride = a.out_stride = 0;
         hipLaunchKernelGGL(corner_select_large, dim3(1), dim3(CH), 0, ctx->stream, a);
     }
     KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
+// ---- a batch of frames ------------------------------------------------------------------------------------
+// goodFeaturesToTrack on the same ROI of n_frames slots with the launches of ONE detection: every kernel of the
+// whole-frame path takes a frame index from its grid.  A single frame leaves the GPU mostly idle (its greedy pass is
+// one workgroup, its sort a few dozen); a batch fills it, and the cost per frame drops by two orders of magnitude.
+// Per frame the result is ktlvo_detect_gftt's for that slot and ROI (same kernels, same keys; the sort runs over the
+// batch's largest candidate count instead of the frame's own, which does not change the order of unique keys).
+// Outputs are device arrays [n_frames][cap]; the host waits once, for the candidate counts that size the sort.
+static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi &roi, const ktlvo_gftt_params *p,
+                             float *d_xy, float *d_resp, int *d_counts, int cap) {
+    const size_t area = (size_t)roi.w * roi.h;
+    if (area * (size_t)n_frames > 0x7fffffff) return KTLVO_ERR_CAPACITY; // candidate offsets are 32-bit
+    std::vector<RoiDev> rois(n_frames);
+    for (int f = 0; f < n_frames; f++) rois[f] = {roi.x, roi.y, roi.w, roi.h, (int)(area * f)};
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // work area: the detector's scratch for n_frames ROIs, then the frames' slot numbers, then their candidate counts' pinned mirror
+    const size_t o_slots = up(corner_scratch_bytes(n_frames, area * n_frames));
+    int rc = ensure_misc(ctx, o_slots + up(4 * (size_t)n_frames));
+    if (rc != KTLVO_OK) return rc;
+    rc = ensure_pin(ctx, 8 * (size_t)n_frames + 8);
+    if (rc != KTLVO_OK) return rc;
+    CornerScratch s;
+    corner_scratch_carve(ctx->d_misc, n_frames, area * n_frames, s);
+    int *d_roi_slots = (int *)((char *)ctx->d_misc + o_slots);
+    int *h_slots = (int *)ctx->h_pin, *h_cnt = h_slots + n_frames, *h_ovf = h_cnt + n_frames;
+    for (int f = 0; f < n_frames; f++) h_slots[f] = slots[f];
+    KTLVO_HIP(ctx, hipMemcpyAsync(d_roi_slots, h_slots, 4 * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
+    rc = corner_scratch_setup(ctx, rois.data(), n_frames, s);
+    if (rc != KTLVO_OK) return rc;
+    rc = run_candidates(ctx, -1, n_frames, roi.w, roi.h, p->use_harris, p->harris_k, s, nullptr, true, d_roi_slots);
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemcpyAsync(h_cnt, s.d_cnt, 4 * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n_sup = 0;
+    for (int f = 0; f < n_frames; f++) n_sup = std::max(n_sup, h_cnt[f]);
+    if (n_sup == 0) {
+        KTLVO_HIP(ctx, hipMemsetAsync(d_counts, 0, 4 * (size_t)n_frames, ctx->stream));
+        *h_ovf = 0;
+        return KTLVO_OK;
+    }
+    size_t np2 = 1;
+    while (np2 < (size_t)n_sup) np2 <<= 1;
+    const bool dist = p->min_dist >= 1;
+    const int cell = dist ? (int)lrint(p->min_dist) : 1;
+    const int gw = dist ? (roi.w + cell - 1) / cell : 0, gh = dist ? (roi.h + cell - 1) / cell : 0;
+    const size_t cells = (size_t)gw * gh;
+    const size_t o_keys = 0, o_n = o_keys + up(np2 * 8 * n_frames), o_cc = o_n + up(4 * (size_t)n_frames);
+    const size_t o_cp = o_cc + up(cells * 4 * n_frames), total = o_cp + up(cells * 16 * n_frames);
+    rc = ensure_aux(ctx, total);
+    if (rc != KTLVO_OK) return rc;
+    char *b = (char *)ctx->d_aux;
+    unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
+    int *d_n = (int *)(b + o_n);
+    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cp, ctx->stream)); // keys, counters, the cells' counts
+    if (dist) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+    const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
+    hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
+                       p->quality, d_keys, d_n, area, np2);
+    KTLVO_HIP(ctx, hipGetLastError());
+    rc = sort_keys(ctx, d_keys, np2, n_frames);
+    if (rc != KTLVO_OK) return rc;
+    const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
+    if (!dist) {
+        hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys, d_n,
+                           roi.w, limit, d_xy, d_resp, d_counts, np2, (size_t)cap);
+    } else {
+        SelLargeArgs a;
+        a.keys = d_keys; a.n_ptr = d_n; a.w = roi.w; a.h = roi.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh;
+        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
+        a.xy = d_xy; a.resp = d_resp; a.count = d_counts; a.overflow = s.d_overflow;
+        a.keys_stride = np2; a.cells_stride = cells; a.out_stride = (size_t)cap;
+        hipLaunchKernelGGL(corner_select_large, dim3((unsigned)n_frames), dim3(CH), 0, ctx->stream, a);
+    }
+    KTLVO_HIP(ctx, hipGetLastError());
+    // the overflow flag lands in pinned memory behind the counts' mirror; a caller that waits for the stream reads it there
+    KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return KTLVO_OK;
+}
+
+static int frames_args_ok(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi_in, const ktlvo_gftt_params *p,
+                          int cap, ktlvo_roi &roi) {
+    if (p->block_size != 3) return KTLVO_ERR_UNSUPPORTED;
+    if (cap <= 0 || p->max_corners > cap) return KTLVO_ERR_INVALID;
+    if (!(p->quality > 0) || !(p->min_dist >= 0)) return KTLVO_ERR_INVALID;
+    if (n_frames > MAX_BATCH) return KTLVO_ERR_CAPACITY;
+    for (int f = 0; f < n_frames; f++) {
+        if (!slot_ok(ctx, slots[f])) return KTLVO_ERR_INVALID;
+        if (ctx->built[slots[f]] < 0) return KTLVO_ERR_STATE;
+    }
+    roi = roi_in ? *roi_in : ktlvo_roi{0, 0, ctx->cfg.width, ctx->cfg.height};
+    if (roi.w <= 0 || roi.h <= 0 || roi.x < 0 || roi.y < 0 || roi.x + roi.w > ctx->cfg.width || roi.y + roi.h > ctx->cfg.height)
+        return KTLVO_ERR_INVALID;
+    if (roi.w > 65535 || roi.h > 65535) return KTLVO_ERR_UNSUPPORTED;
+    if (p->min_dist >= 1) { // four corners per min-distance cell at most: the cell must not be wider than the distance allows
+        const int cell = (int)lrint(p->min_dist);
+        if (cell < 1) return KTLVO_ERR_INVALID;
+    }
     return KTLVO_OK;
 }
 
@@ -811,6 +934,52 @@ extern "C" int ktlvo_detect_gftt_noalloc(ktlvo_ctx *ctx, int slot, const ktlvo_r
     // corner_setup clears the counters the kernels accumulate into; the candidate keys of an earlier call
     // are dead (each ROI reads only the first cand_cnt keys, which this call writes)
     return corner_detect_small_dev(ctx, slot, rois, n_roi, maxw, maxh, p, s, d_xy, d_response, d_counts, cap);
+}
+
+extern "C" int ktlvo_detect_gftt_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi_in,
+                                            const ktlvo_gftt_params *p, float *d_xy, float *d_response, int *d_counts,
+                                            int cap) {
+    if (!ctx || !p || n_frames < 0 || (n_frames > 0 && !slots)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (n_frames == 0) return KTLVO_OK;
+    if (!d_xy || !d_response || !d_counts) return KTLVO_ERR_INVALID;
+    ktlvo_roi roi;
+    int rc = frames_args_ok(ctx, slots, n_frames, roi_in, p, cap, roi);
+    if (rc != KTLVO_OK) return rc;
+    ProfScope ps(ctx, KTLVO_K_CORNER);
+    return detect_frames_dev(ctx, slots, n_frames, roi, p, d_xy, d_response, d_counts, cap);
+}
+
+extern "C" int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi_in,
+                                        const ktlvo_gftt_params *p, float *xy, float *response, int *counts, int cap) {
+    if (!ctx || !p || n_frames < 0 || (n_frames > 0 && !slots)) return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (n_frames == 0) return KTLVO_OK;
+    if (!xy || !response || !counts) return KTLVO_ERR_INVALID;
+    ktlvo_roi roi;
+    int rc = frames_args_ok(ctx, slots, n_frames, roi_in, p, cap, roi);
+    if (rc != KTLVO_OK) return rc;
+    // the results (n_frames x cap points) get a device buffer of their own, kept with the context and grown on demand
+    const size_t b_xy = (size_t)n_frames * cap * 8, b_r = (size_t)n_frames * cap * 4, b_c = 4 * (size_t)n_frames;
+    if (b_xy + b_r + b_c > ctx->frames_out_bytes) {
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_frames_out) KTLVO_HIP(ctx, hipFree(ctx->d_frames_out));
+        ctx->d_frames_out = nullptr; ctx->frames_out_bytes = 0;
+        KTLVO_HIP(ctx, hipMalloc(&ctx->d_frames_out, b_xy + b_r + b_c));
+        ctx->frames_out_bytes = b_xy + b_r + b_c;
+    }
+    float *d_xy = (float *)ctx->d_frames_out, *d_resp = (float *)((char *)ctx->d_frames_out + b_xy);
+    int *d_counts = (int *)((char *)ctx->d_frames_out + b_xy + b_r);
+    ProfScope ps(ctx, KTLVO_K_CORNER);
+    rc = detect_frames_dev(ctx, slots, n_frames, roi, p, d_xy, d_resp, d_counts, cap);
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemcpyAsync(xy, d_xy, b_xy, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(response, d_resp, b_r, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipMemcpyAsync(counts, d_counts, b_c, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int *h_ovf = (const int *)ctx->h_pin + 2 * n_frames;
+    if (*h_ovf) { ctx->last_error = "corner selection: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
+    return KTLVO_OK;
 }
 
 extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *roi, int use_harris, double harris_k,

@@ -211,6 +211,7 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
     if (ctx->d_idx) (void)hipFree(ctx->d_idx);
     if (ctx->d_misc) (void)hipFree(ctx->d_misc);
     if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+    if (ctx->d_frames_out) (void)hipFree(ctx->d_frames_out);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_slab) (void)hipFree(ctx->d_slab);

@@ -100,6 +100,8 @@ struct ktlvo_ctx {
     bool frame_chain = true;    // the frame path's six tracks from one launch (KTLVO_FRAME_PER_STAGE=1 at creation: a launch per stage)
     bool pyr_per_level = false; // one pyrDown launch per level instead of the fused small-level kernel (A/B, tests)
     void *noalloc_scratch = nullptr; // this device's address of the fixed scratch array of ktlvo_detect_gftt_noalloc
+    void *d_frames_out = nullptr; // results of ktlvo_detect_gftt_frames before they go home
+    size_t frames_out_bytes = 0;
     void *d_aux = nullptr;  // sort buffer and cell grid of whole-frame corner selection
     size_t aux_bytes = 0;
     void *h_pin = nullptr;  // pinned host mirror of (part of) the work area: one DMA instead of one per array

@@ -93,6 +93,8 @@ SIGNATURES = {
     "ktlvo_pyrlk_dev": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, C.POINTER(LkParams)]),
     "ktlvo_pyrlk_batch_dev": (_i, [_vp, _ip, _ip, _i, _vp, _i, _vp, _vp, _vp, C.POINTER(LkParams)]),
     "ktlvo_detect_gftt": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
+    "ktlvo_detect_gftt_frames": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
+    "ktlvo_detect_gftt_frames_dev": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_detect_gftt_noalloc": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_corner_response": (_i, [_vp, _i, C.POINTER(Roi), _i, _d, _vp]),
     "ktlvo_anms": (_i, [_vp, _vp, _vp, _ip, _i]),
@@ -337,6 +339,26 @@ class Context:
         self._chk(lib.ktlvo_detect_gftt(self._h, slot, arr, n, C.byref(params), _ptr(xy), _ptr(resp), _ptr(counts),
                                         cap), "ktlvo_detect_gftt")
         return [(xy[i, :counts[i]].copy(), resp[i, :counts[i]].copy()) for i in range(n)]
+
+    def detect_gftt_frames(self, slots, params, roi=None):
+        """The same region (None = whole frame) of several slots in one call; a list of (xy, response) per slot."""
+        n = len(slots)
+        arr = (C.c_int * max(n, 1))(*slots)
+        cap = params.max_corners
+        xy = np.zeros((max(n, 1), cap, 2), np.float32)
+        resp = np.zeros((max(n, 1), cap), np.float32)
+        counts = np.zeros(max(n, 1), np.int32)
+        r = C.byref(Roi(*roi)) if roi is not None else None
+        self._chk(lib.ktlvo_detect_gftt_frames(self._h, arr, n, r, C.byref(params), _ptr(xy), _ptr(resp), _ptr(counts),
+                                               cap), "ktlvo_detect_gftt_frames")
+        return [(xy[i, :counts[i]].copy(), resp[i, :counts[i]].copy()) for i in range(n)]
+
+    def detect_gftt_frames_dev(self, slots, params, d_xy, d_resp, d_counts, cap, roi=None):
+        n = len(slots)
+        arr = (C.c_int * max(n, 1))(*slots)
+        r = C.byref(Roi(*roi)) if roi is not None else None
+        self._chk(lib.ktlvo_detect_gftt_frames_dev(self._h, arr, n, r, C.byref(params), d_xy, d_resp, d_counts, cap),
+                  "ktlvo_detect_gftt_frames_dev")
 
     def detect_gftt_noalloc(self, slot, rois, params, d_xy, d_resp, d_counts, cap):
         """Device-pointer form that allocates nothing; returns the status code (no exception) so that tests

@@ -561,6 +561,49 @@ def test_fused_small_levels_equal_per_level_launches(make_ctx, oracle, size):
     assert 0.05 < ra[1].mean() < 1.0
 
 
+def test_batched_detection_equals_per_frame_detection(make_ctx, klib):
+    """ktlvo_detect_gftt_frames: the whole-frame detector over a batch of frames with the launches of one
+    detection.  Every frame's corners, order and responses equal ktlvo_detect_gftt's for that frame: frames of
+    very different candidate counts in one batch (texture, a nearly flat frame, a flat one), with and without a
+    minimum distance, a region instead of the whole frame, a count no frame can reach, and the device-output form."""
+    import torch
+    W, H, n = 640, 360, 7
+    rng = np.random.default_rng(33)
+    from slam_amd.synth import texture_image
+    imgs = [texture_image(W, H, seed=40 + i) for i in range(4)]
+    imgs.append(np.full((H, W), 90, np.uint8))                                  # flat: no corners
+    low = np.full((H, W), 120, np.uint8)
+    low[100:140, 200:260] = texture_image(60, 40, seed=5)                        # nearly flat: a handful
+    imgs.append(low)
+    imgs.append(rng.integers(0, 256, (H, W), dtype=np.uint8))                    # noise: candidates everywhere
+    ctx = make_ctx(width=W, height=H, num_slots=n)
+    ctx.upload_images(list(range(n)), np.stack(imgs))
+    order = [6, 0, 4, 2, 5, 1, 3, 0]                                             # any order, a slot twice
+    for params, roi in ((klib.gftt_params(800, 0.01, 7.0, 3, 0, 0.0), None),
+                        (klib.gftt_params(3000, 0.02, 0.0, 3, 1, 0.04), None),
+                        (klib.gftt_params(20000, 0.001, 3.0, 3, 0, 0.0), None),
+                        (klib.gftt_params(500, 0.01, 10.0, 3, 0, 0.0), (37, 21, 411, 300))):
+        got = ctx.detect_gftt_frames(order, params, roi)
+        r = roi if roi is not None else (0, 0, W, H)
+        for s, (xy, resp) in zip(order, got):
+            (rxy, rresp), = ctx.detect_gftt(s, [r], params)
+            assert np.array_equal(xy, rxy) and np.array_equal(resp, rresp), (s, len(xy), len(rxy))
+        assert len(got[2][0]) == 0 and 0 < len(got[4][0]) < 200 and len(got[0][0]) > 300
+    params = klib.gftt_params(800, 0.01, 7.0, 3, 0, 0.0)
+    d_xy = torch.zeros((n, 800, 2), device="cuda")
+    d_resp = torch.zeros((n, 800), device="cuda")
+    d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.detect_gftt_frames_dev(list(range(n)), params, d_xy.data_ptr(), d_resp.data_ptr(), d_cnt.data_ptr(), 800)
+    ctx.sync()
+    for s in range(n):
+        (rxy, rresp), = ctx.detect_gftt(s, [(0, 0, W, H)], params)
+        k = int(d_cnt[s])
+        assert k == len(rxy) and np.array_equal(d_xy[s, :k].cpu().numpy(), rxy) and np.array_equal(d_resp[s, :k].cpu().numpy(), rresp)
+    with pytest.raises(klib.KtlvoError) as ei:
+        ctx.detect_gftt_frames([0, n], params)
+    assert ei.value.status == klib.ERR_INVALID
+
+
 def test_batched_upload_equals_per_frame_upload(make_ctx):
     """ktlvo_upload_images (one DMA, one ingest launch) fills the slots exactly as n ktlvo_upload_image calls do,
     from pageable and from pinned memory, into slots given in any order."""
