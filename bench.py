@@ -602,6 +602,36 @@ def main():
 
     tracked = int(d_status.sum().item())           # per step on this rank (deterministic input)
 
+    # ---- the detector on the step's first frames, all in one call (reported beside the step, never part of it) ----
+    # BASELINE's stream detects its corners on every frame.  One frame at a time the whole-frame detector costs
+    # 0.5 ms, forty times the frame's share of the LK launch; ktlvo_detect_gftt_frames_dev runs the batch with
+    # the launches of one detection, corners landing where ktlvo_pyrlk_batch_dev reads them.
+    detect = None
+    if rank == 0 and not a.skip_secondary and NP <= 256:
+        d_cxy = torch.zeros((NP, NF, 2), device=dev)
+        d_cr = torch.zeros((NP, NF), device=dev)
+        d_cc = torch.zeros(NP, dtype=torch.int32, device=dev)
+
+        def detect_all():
+            ctx.detect_gftt_frames_dev(prev_slots, gp, d_cxy.data_ptr(), d_cr.data_ptr(), d_cc.data_ptr(), NF)
+        for _ in range(2):
+            detect_all()
+        ctx.sync()
+        reps = 5
+        t = time.perf_counter()
+        for _ in range(reps):
+            detect_all()
+        ctx.sync()
+        t_det = (time.perf_counter() - t) / reps
+        cc = d_cc.cpu().numpy()
+        (xy0, _), = ctx.detect_gftt(prev_slots[0], [(0, 0, W, H)], gp)
+        assert int(cc[0]) == len(xy0) and np.array_equal(d_cxy[0, :len(xy0)].cpu().numpy(), xy0)
+        detect = {"ms_per_step": t_det * 1e3, "frames": NP, "corners": int(cc.sum()), "us_per_frame": t_det / NP * 1e6,
+                  "note": "ktlvo_detect_gftt_frames_dev: Shi-Tomasi corners (quality 0.01, minDistance %g, at most %d) of the "
+                          "step's %d first frames in one call, output on the device; one frame per call costs %s" % (
+                              a.min_dist, NF, NP, "0.5 ms at this size" if (W, H) == (1241, 376) else "far more")}
+        del d_cxy, d_cr, d_cc
+
     # ---- the same step fed from host memory every time (frame-pair STREAM, never the headline) ------------
     # One batched DMA per step (ktlvo_upload_images from a pinned buffer).  The library issues that DMA on the
     # context's copy stream and unpacks it on the context's stream, so with ONE context the upload of step N+1
@@ -793,6 +823,7 @@ def main():
                 "launches": int(k3_n),
                 "features_per_launch": feats_per_launch,
             },
+            "detect_frames": detect,
             "kernels": {
                 "pyr_down_u8": {"avg_ms_per_step": k1_ms / max(k1_n, 1), "images_per_step": NI,
                                 "algorithmic_bytes_per_image": pyr_bytes,

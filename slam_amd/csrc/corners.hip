@@ -470,8 +470,10 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         if (total0 >= a.limit) break;
         const unsigned long long my_key = next_key;
         if (base + CH + tid < n) next_key = a.keys[base + CH + tid];
-        // what the previous chunk stored must be read from L2, not from this CU's L1
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // What the previous chunk stored into the grid is read here by other waves of the same workgroup: they
+        // run on one CU and share its L1, so workgroup scope orders it (a wider scope would write back and
+        // invalidate the XCD's whole L2 twice per chunk, under every other frame of a batch).
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (int q = tid; q < HT; q += CH) ht_key[q] = 0u;
         // (1) against the grid
         const int i = base + tid;
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                 else *a.overflow = 2; // cannot happen for cell = round(min_dist); reported instead of dropped
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
     }
     if (tid == 0) *a.count = s_total;

@@ -14,7 +14,21 @@ ctx.upload_image(0, img)
 sw, sh = (W - 60) / 20.0, (H - 60) / 8.0
 grid = [(30 + int(sw * j), 30 + int(sh * i), int(sw), int(sh)) for i in range(8) for j in range(20)]
 mode = sys.argv[1] if len(sys.argv) > 1 else "frame"
-for _ in range(5):
+if mode == "batch":  # 254 frames of the sequence in one ktlvo_detect_gftt_frames call, as the benchmark times it
+    import time
+    import numpy as np
+    nf = 254
+    frames = synth.render_corridor_frames(W, H, 0x5EED0002, 128, workers=8)
+    ctx.close()
+    ctx = K.Context(K.default_config(width=W, height=H, num_slots=nf, max_points=4096))
+    ctx.upload_images(list(range(nf)), np.stack([frames[i % 128] for i in range(nf)]))
+    gp = K.gftt_params(2000, 0.01, 10.0, 3, 0, 0.0)
+    for _ in range(4):
+        t = time.perf_counter()
+        out = ctx.detect_gftt_frames(list(range(nf)), gp)
+        dt = time.perf_counter() - t
+    print("batch of %d frames: %.3f ms per call (results to the host)" % (nf, dt * 1e3))
+for _ in range(0 if mode == "batch" else 5):
     if mode == "frame":
         out = ctx.detect_gftt(0, [(0, 0, W, H)], K.gftt_params(2000, 0.01, 10.0, 3, 0, 0.0))
     else:
