@@ -626,7 +626,30 @@ def main():
         cc = d_cc.cpu().numpy()
         (xy0, _), = ctx.detect_gftt(prev_slots[0], [(0, 0, W, H)], gp)
         assert int(cc[0]) == len(xy0) and np.array_equal(d_cxy[0, :len(xy0)].cpu().numpy(), xy0)
+        # the whole stream step: detect on the first frames, build the pyramids, track the detected corners (frames
+        # short of NF corners at this spacing track their list's unused tail as well; only real corners are counted)
+        o_next, o_status, o_err = outs[0]
+
+        def full_step():
+            detect_all()
+            ctx.build_pyramids(slots)
+            ctx.pyrlk_batch_dev(prev_slots, next_slots, d_cxy.data_ptr(), NF, o_next.data_ptr(), o_status.data_ptr(),
+                                o_err.data_ptr(), lk)
+        for _ in range(2):
+            full_step()
+        ctx.sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            full_step()
+        ctx.sync()
+        t_full = (time.perf_counter() - t) / reps
+        real = torch.arange(NF, device=dev)[None, :] < d_cc[:, None].to(torch.int64)
+        tracked_full = int((o_status.bool() & real).sum().item())
+        step()                                   # the resident-input step's outputs back in place
+        ctx.sync()
         detect = {"ms_per_step": t_det * 1e3, "frames": NP, "corners": int(cc.sum()), "us_per_frame": t_det / NP * 1e6,
+                  "detect_build_track": {"ms_per_step": t_full * 1e3, "tracked_per_step": tracked_full,
+                                         "value": tracked_full / t_full, "unit": "tracked features/s"},
                   "note": "ktlvo_detect_gftt_frames_dev: Shi-Tomasi corners (quality 0.01, minDistance %g, at most %d) of the "
                           "step's %d first frames in one call, output on the device; one frame per call costs %s" % (
                               a.min_dist, NF, NP, "0.5 ms at this size" if (W, H) == (1241, 376) else "far more")}
