@@ -122,39 +122,45 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
         cxx[cy][cx] = dx * dx; cxy[cy][cx] = dx * dy; cyy[cy][cx] = dy * dy;
     }
     __syncthreads();
-    // response tile: ROI-relative (tx0 - 1 + px, ty0 - 1 + py), inside the ROI only
+    // response tile: ROI-relative (tx0 - 1 + px, ty0 - 1 + py), inside the ROI only.  cv::boxFilter sums float input
+    // in double, rows first ((a0 + a1) + a2 per row, then (r0 + r1) + r2 down the column).  A thread owns a column
+    // px and a strip of STRIP rows: it walks down the strip's STRIP + 2 covariance rows, forms each row's three sums
+    // once and keeps the last two in registers, so an output costs 1.4 row sums instead of three.
     float vmax = -INFINITY;
-    for (int i = tid; i < CR * CR; i += 256) {
-        const int py = i / CR, px = i - py * CR;
-        const int x = tx0 - 1 + px, y = ty0 - 1 + py;
-        float r = -INFINITY;
-        if (x >= 0 && y >= 0 && x < R.w && y < R.h) {
-            double a = 0, b = 0, c = 0; // cv::boxFilter sums float input in double
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                double ra = 0, rb = 0, rc = 0;
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    ra += (double)cxx[py + j][px + q];
-                    rb += (double)cxy[py + j][px + q];
-                    rc += (double)cyy[py + j][px + q];
+    constexpr int STRIP = 5, NSTRIP = (CR + STRIP - 1) / STRIP;
+    if (tid < CR * NSTRIP) {
+        const int st = tid / CR, px = tid - st * CR;
+        const int py0 = st * STRIP, rows = min(STRIP, CR - py0);
+        const int x = tx0 - 1 + px;
+        double r0a = 0, r0b = 0, r0c = 0, r1a = 0, r1b = 0, r1c = 0;
+        for (int j = 0; j < rows + 2; j++) {
+            const int cy = py0 + j;
+            double sa = (double)cxx[cy][px], sb = (double)cxy[cy][px], sc = (double)cyy[cy][px];
+            sa += (double)cxx[cy][px + 1]; sb += (double)cxy[cy][px + 1]; sc += (double)cyy[cy][px + 1];
+            sa += (double)cxx[cy][px + 2]; sb += (double)cxy[cy][px + 2]; sc += (double)cyy[cy][px + 2];
+            if (j >= 2) {
+                const int py = cy - 2, y = ty0 - 1 + py;
+                float r = -INFINITY;
+                if (x >= 0 && y >= 0 && x < R.w && y < R.h) {
+                    const double a = (r0a + r1a) + sa, b = (r0b + r1b) + sb, c = (r0c + r1c) + sc;
+                    const float fa = (float)a, fb = (float)b, fc = (float)c;
+                    if (harris) {
+                        const float t = fa * fc - fb * fb;
+                        r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
+                    } else {
+                        const float ha = fa * 0.5f, hc = fc * 0.5f;
+                        r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
+                    }
+                    if (px >= 1 && py >= 1 && px <= CT && py <= CT) { // this workgroup's own pixels
+                        vmax = fmaxf(vmax, r);
+                        if (resp_out) resp_out[R.off + y * R.w + x] = r;
+                    }
                 }
-                a += ra; b += rb; c += rc;
+                rsp[py][px] = r;
             }
-            const float fa = (float)a, fb = (float)b, fc = (float)c;
-            if (harris) {
-                const float t = fa * fc - fb * fb;
-                r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
-            } else {
-                const float ha = fa * 0.5f, hc = fc * 0.5f;
-                r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
-            }
-            if (px >= 1 && py >= 1 && px <= CT && py <= CT) { // this workgroup's own pixels
-                vmax = fmaxf(vmax, r);
-                if (resp_out) resp_out[R.off + y * R.w + x] = r;
-            }
+            r0a = r1a; r0b = r1b; r0c = r1c;
+            r1a = sa; r1b = sb; r1c = sc;
         }
-        rsp[py][px] = r;
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(&roi_max[roi_id], f2ord(vmax));
