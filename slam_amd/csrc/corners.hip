@@ -879,10 +879,6 @@ static int frames_args_ok(ktlvo_ctx *ctx, const int *slots, int n_frames, const 
     if (roi.w <= 0 || roi.h <= 0 || roi.x < 0 || roi.y < 0 || roi.x + roi.w > ctx->cfg.width || roi.y + roi.h > ctx->cfg.height)
         return KTLVO_ERR_INVALID;
     if (roi.w > 65535 || roi.h > 65535) return KTLVO_ERR_UNSUPPORTED;
-    if (p->min_dist >= 1) { // four corners per min-distance cell at most: the cell must not be wider than the distance allows
-        const int cell = (int)lrint(p->min_dist);
-        if (cell < 1) return KTLVO_ERR_INVALID;
-    }
     return KTLVO_OK;
 }
 
