@@ -75,7 +75,20 @@ def test_pyramid_scharr_lk_random_sizes(make_ctx, oracle, klib):
                 # adds 63 integer partials in a tree, the oracle 441 floats serially) grow over up to 150
                 # steps; the bulk must still agree, and the residual must agree where the position does
                 # (on white noise it changes by up to a hundred-odd grey levels per pixel of displacement)
-                assert np.quantile(d, 0.95) <= 0.05, (w, h, np.quantile(d, 0.95))
+                if np.quantile(d, 0.95) > 0.05:
+                    # a frame on which the order of the float additions alone moves that many points that far
+                    # (a long sweep finds one in a few hundred): the kernel must then be no further from the
+                    # serial oracle than the oracle is from itself with pairwise sums
+                    oracle.set_lk_sum_mode(2)
+                    try:
+                        po_, ps_, _ = oracle.pyrlk(a, b, pts, nthreads=8)
+                    finally:
+                        oracle.set_lk_sum_mode(0)
+                    ok = both & (ps_ == 1)
+                    d_gpu, d_ord = np.abs(go - oo).max(1)[ok], np.abs(po_ - oo).max(1)[ok]
+                    assert np.quantile(d_gpu, 0.95) <= 1.5 * np.quantile(d_ord, 0.95), (w, h, np.quantile(d_gpu, 0.95),
+                                                                                      np.quantile(d_ord, 0.95))
+                    assert (d_gpu > 0.05).sum() <= 1.5 * (d_ord > 0.05).sum() + 2, (w, h)
                 assert np.all(de <= 0.05 + 200.0 * d), (w, h, float((de - 200.0 * d).max()))
             checked += int(both.sum())
         lost = agree & (gs == 0)
