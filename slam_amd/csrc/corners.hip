@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
     const int tx0 = (tr % tiles_x) * CT, ty0 = (tr / tiles_x) * CT;
     if (tx0 >= R.w || ty0 >= R.h) return;
     const LevelDesc L = slots[roi_slots ? roi_slots[roi_id] : slot].lv[0]; // a batch of frames: every ROI names its slot
-    __shared__ uint8_t img[CI][CI + 2];
+    __shared__ __attribute__((aligned(16))) uint8_t img[CI][CI + 2]; // rows of 40 bytes: filled a dword at a time
     __shared__ float cxx[CC][CC + 1], cxy[CC][CC + 1], cyy[CC][CC + 1];
     __shared__ float rsp[CR][CR + 1];
     __shared__ int wave_cnt[4][4];
@@ -97,29 +97,58 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
 
     // image tile: ROI-relative (tx0 - 3 + ix, ty0 - 3 + iy).  Sobel reads the PARENT image beyond the ROI
     // (cv::Sobel on a view is not BORDER_ISOLATED; the level's reflect-101 frame is materialised), so the
-    // tile is fetched unreflected; only the pixels a covariance sample can touch are needed.
-    for (int i = tid; i < CI * CI; i += 256) {
-        const int iy = i / CI, ix = i - iy * CI;
-        const int rx = tx0 - 3 + ix, ry = ty0 - 3 + iy;
-        uint8_t v = 0;
-        if (rx >= -1 && rx <= R.w && ry >= -1 && ry <= R.h) v = L.origin[(ptrdiff_t)(R.y + ry) * L.pitch + (R.x + rx)];
-        img[iy][ix] = v;
+    // tile is fetched unreflected, four bytes per load at whatever byte address the tile's rows start.  Only pixels
+    // within one of the ROI can reach a result; rows are kept inside the plane's frame, and a row's last bytes may
+    // come from beyond its own frame (the next row's), which is memory of the same plane.
+    {
+        typedef const __attribute__((address_space(1))) uint8_t *gsrc;
+        typedef uint32_t u32_a1 __attribute__((aligned(1)));
+        const gsrc base = (gsrc)L.origin + (R.x + tx0 - 3);
+        const int last_row = L.h + PAD - 1;
+        for (int i = tid; i < CI * (CI + 2) / 4; i += 256) {
+            const int iy = i / ((CI + 2) / 4), k = i - iy * ((CI + 2) / 4);
+            const int row = min(R.y + ty0 - 3 + iy, last_row);
+            *(uint32_t *)&img[iy][4 * k] = *(const __attribute__((address_space(1))) u32_a1 *)(base + (ptrdiff_t)row * L.pitch + 4 * k);
+        }
     }
     __syncthreads();
     // covariance tile: ROI-relative (tx0 - 2 + cx, ty0 - 2 + cy); the box filter runs on the ROI-sized
-    // covariance image and reflects at the ROI's own edges
-    for (int i = tid; i < CC * CC; i += 256) {
-        const int cy = i / CC, cx = i - cy * CC;
-        const int x = reflect101d(tx0 - 2 + cx, R.w) - (tx0 - 3), y = reflect101d(ty0 - 2 + cy, R.h) - (ty0 - 3);
-        const float a00 = img[y - 1][x - 1], a01 = img[y - 1][x], a02 = img[y - 1][x + 1];
-        const float a10 = img[y][x - 1], a12 = img[y][x + 1];
-        const float a20 = img[y + 1][x - 1], a21 = img[y + 1][x], a22 = img[y + 1][x + 1];
-        const float r0 = a02 - a00, r1 = a12 - a10, r2 = a22 - a20;
-        const float dx = (r0 + r2) * s1 + r1 * s2;
-        float q0 = s1 * a00; q0 += s2 * a01; q0 += s1 * a02;
-        float q2 = s1 * a20; q2 += s2 * a21; q2 += s1 * a22;
-        const float dy = q2 - q0;
-        cxx[cy][cx] = dx * dx; cxy[cy][cx] = dx * dy; cyy[cy][cx] = dy * dy;
+    // covariance image and reflects at the ROI's own edges.  The Sobel pair separates by rows: with
+    // d(row) = a[x+1] - a[x-1] and q(row) = s1 a[x-1] + s2 a[x] + s1 a[x+1], dx = (d(y-1) + d(y+1)) s1 + d(y) s2 and
+    // dy = q(y+1) - q(y-1).  A thread owns a column cx and a strip of S2 rows: it walks down the strip's S2 + 2 image
+    // rows, forms d and q of a row once and keeps the last two rows' in registers.  A column beyond the ROI's edge
+    // takes its mirror column's pixels right away; the two ROWS beyond the ROI's edges that a response can reach
+    // (-1 and R.h) are copied from their mirror rows afterwards.
+    constexpr int S2 = 6;
+    static_assert(CC % S2 == 0, "strips tile the covariance rows");
+    if (tid < CC * (CC / S2)) {
+        const int st = tid / CC, cx = tid - st * CC, cy0 = st * S2;
+        const int x = reflect101d(tx0 - 2 + cx, R.w) - (tx0 - 3);
+        float d0 = 0.f, d1 = 0.f, q0 = 0.f, q1 = 0.f; // rows iy - 2 and iy - 1
+#pragma unroll
+        for (int j = 0; j < S2 + 2; j++) {
+            const int iy = cy0 + j; // image-tile row; covariance row cy reads image rows cy, cy + 1, cy + 2
+            const float am = img[iy][x - 1], a0 = img[iy][x], ap = img[iy][x + 1];
+            const float d2 = ap - am;
+            float q2 = s1 * am; q2 += s2 * a0; q2 += s1 * ap;
+            if (j >= 2) {
+                const int cy = iy - 2;
+                const float dx = (d0 + d2) * s1 + d1 * s2;
+                const float dy = q2 - q0;
+                cxx[cy][cx] = dx * dx; cxy[cy][cx] = dx * dy; cyy[cy][cx] = dy * dy;
+            }
+            d0 = d1; d1 = d2; q0 = q1; q1 = q2;
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * CC) {
+        const int which = tid / CC, cx = tid - which * CC;
+        const int yy = which ? R.h : -1;                     // ROI-relative row beyond the edge
+        const int cy = yy - (ty0 - 2);                       // its place in the tile, if the tile reaches it ...
+        const int my = reflect101d(yy, R.h) - (ty0 - 2);     // ... and its mirror row's
+        if (cy >= 0 && cy < CC && my >= 0 && my < CC) {
+            cxx[cy][cx] = cxx[my][cx]; cxy[cy][cx] = cxy[my][cx]; cyy[cy][cx] = cyy[my][cx];
+        }
     }
     __syncthreads();
     // response tile: ROI-relative (tx0 - 1 + px, ty0 - 1 + py), inside the ROI only.  cv::boxFilter sums float input
@@ -171,23 +200,22 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
     // Candidates are counted per wave (ballot), the counts meet in LDS and the workgroup takes its places
     // in the ROI's list with ONE global atomic: returning atomics on a single address serialise in L2.
     // The order of candidates in the list does not matter: the keys are sorted later and are unique.
+    // A thread owns column ox and four rows: it forms the maximum of each of its six response rows' three entries
+    // once and combines three of them per pixel.
     const int lane = tid & 63, wave = tid >> 6;
+    const int ox = tid % CT, oy0 = (tid / CT) * 4;
     unsigned long long votes[4];
     float vals[4];
+    float rm[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) rm[j] = fmaxf(fmaxf(rsp[oy0 + j][ox], rsp[oy0 + j][ox + 1]), rsp[oy0 + j][ox + 2]);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int i = tid + 256 * q, oy = i / CT, ox = i - oy * CT;
+        const int oy = oy0 + q;
         const int x = tx0 + ox, y = ty0 + oy;
         const float v = rsp[oy + 1][ox + 1];
-        bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1 && v > 0.f;
-        if (keep) {
-            float m = v;
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int p = 0; p < 3; p++) m = fmaxf(m, rsp[oy + j][ox + p]);
-            keep = v == m;
-        }
+        const float m = fmaxf(fmaxf(rm[q], rm[q + 1]), rm[q + 2]);
+        const bool keep = x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1 && v > 0.f && v == m;
         vals[q] = v;
         votes[q] = __ballot(keep);
         if (lane == 0) wave_cnt[wave][q] = __popcll(votes[q]);
@@ -205,7 +233,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (!((votes[q] >> lane) & 1ull)) continue;
-        const int i = tid + 256 * q, oy = i / CT, ox = i - oy * CT;
+        const int oy = oy0 + q;
         const int place = block_base + wave_cnt[wave][q] + __popcll(votes[q] & ((1ull << lane) - 1ull));
         cand[R.off + place] = ((unsigned long long)f2ord(vals[q]) << 32) | (unsigned)((ty0 + oy) * R.w + (tx0 + ox));
     }
