@@ -416,9 +416,15 @@ __device__ __forceinline__ void bitonic_lds_steps(unsigned long long *s, int n_l
         __syncthreads();
     }
 }
-// (blockIdx.y selects one of several lists sorted by the same launch, list_stride keys apart)
-__global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *keys, int np2, size_t list_stride) {
+// (blockIdx.y selects one of several lists sorted by the same launch, list_stride keys apart.  A list's keys sit at
+// its front and the rest is zero, the smallest key; n_used[list] says how many there are.  The steps that build
+// sorted runs of length k move keys only inside aligned runs of k, so before and during them every key beyond n_used
+// rounded up to a multiple of k is still zero; a compare-exchange between two zeros changes nothing, and blocks and
+// pairs out there are skipped: the network is the same, only its idle part is not executed.)
+__global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *keys, int np2, size_t list_stride,
+                                                           const int *n_used) {
     keys += blockIdx.y * list_stride;
+    if ((size_t)blockIdx.x * BL >= (size_t)n_used[blockIdx.y]) return;
     __shared__ unsigned long long s[BL];
     const int n_local = np2 < BL ? np2 : BL;
     const size_t gbase = (size_t)blockIdx.x * BL;
@@ -427,8 +433,10 @@ __global__ __launch_bounds__(1024) void bitonic_local_sort(unsigned long long *k
     for (int k = 2; k <= n_local; k <<= 1) bitonic_lds_steps(s, n_local, gbase, (size_t)k, k >> 1);
     for (int i = threadIdx.x; i < n_local; i += blockDim.x) keys[gbase + i] = s[i];
 }
-__global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *keys, unsigned k, size_t list_stride) {
+__global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *keys, unsigned k, size_t list_stride,
+                                                            const int *n_used) {
     keys += blockIdx.y * list_stride;
+    if ((size_t)blockIdx.x * BL >= (((size_t)n_used[blockIdx.y] + k - 1) & ~((size_t)k - 1))) return;
     __shared__ unsigned long long s[BL];
     const size_t gbase = (size_t)blockIdx.x * BL;
     for (int i = threadIdx.x; i < BL; i += blockDim.x) s[i] = keys[gbase + i];
@@ -436,11 +444,13 @@ __global__ __launch_bounds__(1024) void bitonic_local_merge(unsigned long long *
     bitonic_lds_steps(s, BL, gbase, (size_t)k, BL >> 1);
     for (int i = threadIdx.x; i < BL; i += blockDim.x) keys[gbase + i] = s[i];
 }
-__global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *keys, unsigned j, unsigned k, size_t list_stride) {
+__global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *keys, unsigned j, unsigned k, size_t list_stride,
+                                                           const int *n_used) {
     keys += blockIdx.y * list_stride;
     // thread t owns the pair (i, i | j) with i = t with a zero bit inserted at position log2(j)
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t i = ((t & ~((size_t)j - 1)) << 1) | (t & ((size_t)j - 1));
+    if (i >= (((size_t)n_used[blockIdx.y] + k - 1) & ~((size_t)k - 1))) return; // i and i | j both lie in the zeros
     const size_t p = i | j;
     const unsigned long long x = keys[i], y = keys[p];
     const bool desc = (i & k) == 0;
@@ -755,14 +765,17 @@ static int ensure_aux(ktlvo_ctx *ctx, size_t bytes) {
 }
 
 // n_lists lists of np2 keys each (np2 a power of two), back to back, each sorted descending.
-static int sort_keys(ktlvo_ctx *ctx, unsigned long long *d_keys, size_t np2, int n_lists) {
+// d_n_used[list] = number of keys at the front of the list, the rest being zero.
+static int sort_keys(ktlvo_ctx *ctx, unsigned long long *d_keys, size_t np2, int n_lists, const int *d_n_used) {
     const unsigned L = (unsigned)n_lists;
-    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL), L), dim3(1024), 0, ctx->stream, d_keys, (int)np2, np2);
+    hipLaunchKernelGGL(bitonic_local_sort, dim3((unsigned)((np2 + BL - 1) / BL), L), dim3(1024), 0, ctx->stream, d_keys, (int)np2, np2,
+                       d_n_used);
     for (size_t k = 2 * (size_t)BL; k <= np2; k <<= 1) {
         for (size_t j = k >> 1; j >= (size_t)BL; j >>= 1)
             hipLaunchKernelGGL(bitonic_global_step, dim3((unsigned)(np2 / 512), L), dim3(256), 0, ctx->stream, d_keys, (unsigned)j,
-                               (unsigned)k, np2);
-        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL), L), dim3(1024), 0, ctx->stream, d_keys, (unsigned)k, np2);
+                               (unsigned)k, np2, d_n_used);
+        hipLaunchKernelGGL(bitonic_local_merge, dim3((unsigned)(np2 / BL), L), dim3(1024), 0, ctx->stream, d_keys, (unsigned)k, np2,
+                           d_n_used);
     }
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
@@ -797,7 +810,7 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
                        p->quality, d_keys, d_n, (size_t)0, (size_t)0);
     KTLVO_HIP(ctx, hipGetLastError());
     // How many passed is only known on the device; the sort is sized for the candidate count, which bounds it.
-    rc = sort_keys(ctx, d_keys, np2, 1);
+    rc = sort_keys(ctx, d_keys, np2, 1, d_n);
     if (rc != KTLVO_OK) return rc;
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     if (!dist) {
@@ -873,7 +886,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
                        p->quality, d_keys, d_n, area, np2);
     KTLVO_HIP(ctx, hipGetLastError());
-    rc = sort_keys(ctx, d_keys, np2, n_frames);
+    rc = sort_keys(ctx, d_keys, np2, n_frames, d_n);
     if (rc != KTLVO_OK) return rc;
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     if (!dist) {
