@@ -117,11 +117,11 @@ def parse():
     ap.add_argument("--pairs", type=int, default=127, help="consecutive frame pairs per sequence and step (<= 127)")
     ap.add_argument("--sequences", type=int, default=2,
                     help="synthetic sequences per rank and step (sequences x pairs <= 256, the capacity of one LK launch)")
-    ap.add_argument("--features", type=int, default=2000)
-    ap.add_argument("--width", type=int, default=1241)
-    ap.add_argument("--height", type=int, default=376)
+    ap.add_argument("--features", type=int, default=None, help="corners per frame (default 2000; batch workload 16384)")
+    ap.add_argument("--width", type=int, default=None, help="default 1241; batch workload 3840")
+    ap.add_argument("--height", type=int, default=None, help="default 376; batch workload 2160")
     ap.add_argument("--max-level", type=int, default=4)
-    ap.add_argument("--min-dist", type=float, default=10.0)
+    ap.add_argument("--min-dist", type=float, default=None, help="default 10; batch workload 8")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline time budget (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="contexts (each with its own stream and slots) the steps alternate between, so one "
@@ -150,7 +150,14 @@ def parse():
     ap.add_argument("--dump-trajectories", default="", help="sequence workload: rank 0 saves the gathered poses here (.npy)")
     ap.add_argument("--streams", type=int, default=1,
                     help="sequence workload: tracker instances per GPU, one host thread and one HIP stream each")
-    return ap.parse_args()
+    a = ap.parse_args()
+    # shapes left open take the workload's BASELINE shape: configs[4] for the fixed batch, configs[1] otherwise
+    shape = (3840, 2160, 16384, 8.0) if a.workload == "batch" else (1241, 376, 2000, 10.0)
+    if a.width is None: a.width = shape[0]
+    if a.height is None: a.height = shape[1]
+    if a.features is None: a.features = shape[2]
+    if a.min_dist is None: a.min_dist = shape[3]
+    return a
 
 
 def run_sequence(a, rank, world, local, dev):
@@ -303,9 +310,12 @@ def run_batch(a, rank, world, local, dev):
     n_loc = len(mine)
     assert n_loc <= 256
     pyr_bytes, levels = pyramid_bytes(W, H, a.max_level)
-    frames = []
-    for p in mine:
-        frames += synth.render_corridor_frames(W, H, (0x5EED0100 + p) & 0xFFFFFFFF, 2, workers=2)
+    # (the renderer runs in child processes; eight pairs are rendered at a time)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        rendered = list(pool.map(lambda p: synth.render_corridor_frames(W, H, (0x5EED0100 + p) & 0xFFFFFFFF, 2, workers=2), mine))
+    frames = [f for pair in rendered for f in pair]
+    del rendered
     cfg = K.default_config(width=W, height=H, num_slots=max(2 * n_loc, 1), max_level=a.max_level,
                            max_points=max(NF, 1024), cx=601.8873 + (W - 1242) * 0.5, cy=183.1104 + (H - 375) * 0.5)
     ctx = K.Context(cfg, device=local)
