@@ -825,9 +825,16 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     dim3 grid((unsigned)(n_pairs * a.blocks_per_pair));
     ProfScope ps(ctx, KTLVO_K_PYRLK);
     // the reference's maxLevel (featureTracking.cpp:208) gets the unrolled kernel
-    if (max_level == 4) hipLaunchKernelGGL(pyrlk_track_w21<4>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
-    else if (max_level == 3) hipLaunchKernelGGL(pyrlk_track_w21<3>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(pyrlk_track_w21<-1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a);
+    // (level counts up to the reference's get a kernel of their own, with the level loop unrolled; deeper pyramids
+    // share the looping one, which spills a few registers at eight waves per SIMD)
+    switch (max_level) {
+    case 4: hipLaunchKernelGGL(pyrlk_track_w21<4>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL(pyrlk_track_w21<3>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL(pyrlk_track_w21<2>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    case 1: hipLaunchKernelGGL(pyrlk_track_w21<1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    case 0: hipLaunchKernelGGL(pyrlk_track_w21<0>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(pyrlk_track_w21<-1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    }
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }
