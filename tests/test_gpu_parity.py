@@ -602,6 +602,20 @@ def test_batched_detection_equals_per_frame_detection(make_ctx, klib):
     with pytest.raises(klib.KtlvoError) as ei:
         ctx.detect_gftt_frames([0, n], params)
     assert ei.value.status == klib.ERR_INVALID
+    assert ctx.detect_gftt_frames([], params) == []                      # nothing to do is not an error
+    with pytest.raises(klib.KtlvoError) as ei:                            # a region that leaves the frame
+        ctx.detect_gftt_frames([0], params, (600, 0, 100, 100))
+    assert ei.value.status == klib.ERR_INVALID
+    with pytest.raises(klib.KtlvoError) as ei:                            # block sizes other than the reference's
+        ctx.detect_gftt_frames([0], klib.gftt_params(100, 0.01, 5.0, 5, 0, 0.0))
+    assert ei.value.status == klib.ERR_UNSUPPORTED
+    with pytest.raises(klib.KtlvoError) as ei:                            # more frames than one launch takes
+        ctx.detect_gftt_frames([0] * 257, params)
+    assert ei.value.status == klib.ERR_CAPACITY
+    empty = make_ctx(width=W, height=H, num_slots=2)
+    with pytest.raises(klib.KtlvoError) as ei:                            # a slot that holds no image yet
+        empty.detect_gftt_frames([0, 1], params)
+    assert ei.value.status == klib.ERR_STATE
 
 
 def test_batched_upload_equals_per_frame_upload(make_ctx):
