@@ -617,7 +617,7 @@ def main():
     # 0.5 ms, forty times the frame's share of the LK launch; ktlvo_detect_gftt_frames_dev runs the batch with
     # the launches of one detection, corners landing where ktlvo_pyrlk_batch_dev reads them.
     detect = None
-    if rank == 0 and not a.skip_secondary and NP <= 256:
+    if world == 1 and not a.skip_secondary and NP <= 256:   # single-GPU runs only: the other ranks would wait for it
         d_cxy = torch.zeros((NP, NF, 2), device=dev)
         d_cr = torch.zeros((NP, NF), device=dev)
         d_cc = torch.zeros(NP, dtype=torch.int32, device=dev)
@@ -671,7 +671,7 @@ def main():
     # (called as soon as step N is queued) runs under step N's kernels.  Measured: every step waited for (nothing
     # overlaps), one context running ahead, and three contexts taken in turn (a stream each).
     streamed = None
-    if rank == 0 and not a.skip_stream:
+    if world == 1 and not a.skip_stream:
         host = torch.from_numpy(np.stack(frames)).pin_memory()
         NS = 3
         two = list(ctxs[:NS]) + [K.Context(cfg, device=local) for _ in range(NS - min(NS, len(ctxs)))]
