@@ -127,9 +127,9 @@ def parse():
                     help="contexts (each with its own stream and slots) the steps alternate between, so one "
                          "step's pyramid build overlaps the previous step's LK tail")
     ap.add_argument("--skip-stream", action="store_true", help="leave out the host-fed (PCIe-inclusive) measurement")
-    ap.add_argument("--soak", type=float, default=0.0,
-                    help="seconds of extra back-to-back steps after the measurement (keeps the GPU busy long enough for "
-                         "an external sampler such as rocm-smi to see it); reported separately")
+    ap.add_argument("--soak", type=float, default=4.0,
+                    help="seconds of extra back-to-back steps after the measurement (a sustained rate, and long enough "
+                         "for an external sampler such as rocm-smi to see the GPU busy); reported separately, 0 = none")
     ap.add_argument("--skip-secondary", action="store_true",
                     help="leave out the maxLevel-3 run (profiling passes: one launch shape per kernel)")
     ap.add_argument("--time-kernels", choices=["lk", "all"], default="lk",

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_r02
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-seconds 0 --skip-secondary --skip-stream"
+B="python3 $R/bench.py --cpu-seconds 0 --skip-secondary --skip-stream --soak 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B --steps 20 --warmup 3 > $O/trace.log 2>&1
 grep '"metric"' $O/trace.log > $O/bench_under_trace.json || true
 pass() { # name, counters...
