@@ -12,7 +12,10 @@
 //   cand_filter, bitonic_*, corner_select_large
 //                         the same for larger ROIs (whole frames): keys above the threshold are
 //                         compacted, sorted in global memory, and one workgroup runs the greedy pass
-//                         over chunks of 512 candidates against a cell grid in global memory
+//                         over chunks of 512 candidates against a cell grid, which lives in LDS when it
+//                         fits and in global memory otherwise
+//   corner_sort_frames    a batch of frames: one workgroup per frame compacts and sorts the frame's keys
+//                         wholly in LDS (up to 16384 keys; the global sort takes over beyond)
 //
 // goodFeaturesToTrack thresholds the response map at quality * max (THRESH_TOZERO), dilates it 3x3 and
 // keeps pixels that equal the dilated value.  For a pixel above a non-negative threshold that is the
@@ -457,14 +460,76 @@ __global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *k
     if (desc ? x < y : x > y) { keys[i] = y; keys[p] = x; }
 }
 
+// Filter and sort of one frame's candidates by ONE workgroup, wholly in LDS (blockIdx.x = frame of a batch): the keys
+// above the frame's threshold are compacted into LDS as they are read, padded with zeros to a power of two and sorted
+// descending by the same bitonic network; the first out_cnt keys go to out[].  For frames of up to SORT_CAP keys above
+// the threshold (128 KiB of LDS) this replaces cand_filter, the clearing of the key buffer and the dozen launches of
+// the global sort, and nothing has to be sized on the host, so the host need not wait for the candidate counts.  A
+// frame with more keys is left alone: its count is set to zero and *too_many is raised, and the caller runs the global
+// path instead.
+constexpr int SORT_CAP = 16384;
+__global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long long *cand, const int *cand_cnt,
+                                                           const unsigned *roi_max, double quality, unsigned long long *out,
+                                                           int *out_cnt, size_t cand_stride, size_t out_stride, int *too_many) {
+    extern __shared__ unsigned long long sk[]; // SORT_CAP keys
+    __shared__ int s_n;
+    cand += blockIdx.x * cand_stride; out += blockIdx.x * out_stride;
+    const int n = cand_cnt[blockIdx.x];
+    const float thr = roi_threshold(roi_max[blockIdx.x], quality);
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) { // uniform trip count
+        const int i = base + tid;
+        unsigned long long key = 0;
+        bool keep = false;
+        if (i < n) {
+            key = cand[i];
+            keep = ord2f((unsigned)(key >> 32)) > thr;
+        }
+        const unsigned long long vote = __ballot(keep);
+        int woff = 0;
+        if (lane == 0 && vote) woff = atomicAdd(&s_n, __popcll(vote));
+        woff = __builtin_amdgcn_readfirstlane(woff);
+        if (keep) {
+            const int p = woff + __popcll(vote & ((1ull << lane) - 1ull));
+            if (p < SORT_CAP) sk[p] = key;
+        }
+    }
+    __syncthreads();
+    const int m = s_n;
+    if (m > SORT_CAP) {
+        if (tid == 0) { out_cnt[blockIdx.x] = 0; *too_many = 1; }
+        return;
+    }
+    int np2 = 2;
+    while (np2 < m) np2 <<= 1;
+    for (int i = m + tid; i < np2; i += 1024) sk[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            // thread t owns the pairs (i, i | j), i = t' with a zero bit inserted at position log2(j), t' = t, t + 1024, ...
+#pragma unroll 4
+            for (int t = tid; t < (np2 >> 1); t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const unsigned long long x = sk[i], y = sk[p];
+                const bool desc = (i & k) == 0;
+                if (desc ? x < y : x > y) { sk[i] = y; sk[p] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < m; i += 1024) out[i] = sk[i];
+    if (tid == 0) out_cnt[blockIdx.x] = m;
+}
+
 struct SelLargeArgs {
     const unsigned long long *keys; // sorted descending
     const int *n_ptr;               // number of keys above the threshold
     int w, h;
     double min_dist;
     int cell, gw, gh;
-    int *cell_cnt;   // gw * gh, cleared
-    uint4 *cell_pts; // gw * gh: up to four accepted corners as x | y << 16, empty places 0xFFFFFFFF
+    int *cell_cnt;   // gw * gh, cleared                                         (grid in global memory only)
+    uint4 *cell_pts; // gw * gh: up to four accepted corners as x | y << 16, empty places 0xFFFFFFFF   (likewise)
     int limit;
     float *xy, *resp;
     int *count;
@@ -474,22 +539,35 @@ struct SelLargeArgs {
 };
 constexpr int CH = 512;  // candidates per chunk of the greedy pass
 constexpr int HT = 2048; // chunk-local hash of the survivors' cells (load factor <= 1/4)
+// Grid in LDS: a count (4 bytes) and four places of 2 bytes per cell, a corner being kept as its offset inside its
+// cell (x | y << 8, empty 0xFFFF), which a cell of up to 256 pixels allows.
+constexpr size_t SEL_LDS_PER_CELL = 12;
+constexpr size_t SEL_LDS_GRID_MAX = (size_t)104 << 10; // what the kernel's static arrays leave of a compute unit's 160 KiB
+static bool grid_fits_lds(int cell, int gw, int gh) {
+    return cell <= 256 && (size_t)gw * gh * SEL_LDS_PER_CELL <= SEL_LDS_GRID_MAX;
+}
 
 // goodFeaturesToTrack's greedy pass: walk the candidates in sorted order and accept one unless an accepted
 // corner lies closer than min_dist.  A candidate's fate depends only on the accepted corners ranked before
 // it, so a chunk of CH consecutive candidates is handled in parallel: (1) every candidate is tested
-// against the corners accepted from earlier chunks (cell grid in global memory, owned by this single
-// workgroup; the nine cells around a candidate are nine independent 16-byte loads); (2) the survivors are
+// against the corners accepted from earlier chunks (the cell grid, owned by this single workgroup; the nine
+// cells around a candidate are nine independent loads); (2) the survivors are
 // compacted in rank order, entered into a hash of their cells in LDS, and each finds, in the nine cells
 // around it, the survivors ranked before it that are too close (a bit mask per survivor); (3) rounds in
 // which a survivor with an accepted predecessor in its mask is rejected, and one whose predecessors are
 // all rejected is accepted, until all are decided -- the lowest undecided survivor always decides, and
 // chains are short because a chunk's candidates are scattered over the frame; (4) the accepted ones take
 // their output places in rank order and enter the grid.
+// LG: the grid lives in LDS (dynamic: gw * gh * SEL_LDS_PER_CELL bytes), where a look-up costs a fraction of the L2
+// round trip that bounds a chunk otherwise; frames whose grid does not fit keep it in global memory.
+template <bool LG>
 __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     a.keys += blockIdx.x * a.keys_stride; a.n_ptr += blockIdx.x; a.count += blockIdx.x;
-    a.cell_cnt += blockIdx.x * a.cells_stride; a.cell_pts += blockIdx.x * a.cells_stride;
+    if (!LG) { a.cell_cnt += blockIdx.x * a.cells_stride; a.cell_pts += blockIdx.x * a.cells_stride; }
     a.xy += blockIdx.x * a.out_stride * 2; a.resp += blockIdx.x * a.out_stride;
+    extern __shared__ unsigned char dyn_lds[];
+    int *const g_cnt = (int *)dyn_lds;                                            // LG: gw * gh counts ...
+    unsigned short *const g_pts = (unsigned short *)(dyn_lds + 4 * (size_t)a.gw * a.gh); // ... then gw * gh * 4 places
     __shared__ unsigned long long s_key[CH];
     __shared__ int s_x[CH], s_y[CH];
     __shared__ unsigned conf[CH][CH / 32];
@@ -502,11 +580,17 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     const int n = *a.n_ptr;
     const float md = (float)a.min_dist;
     const double md2 = a.min_dist * a.min_dist;
-    auto too_close = [&](int x, int y, unsigned p) {
-        const float dx = (float)x - (float)(p & 0xffff), dy = (float)y - (float)(p >> 16);
+    auto too_close_xy = [&](int x, int y, int px, int py) {
+        const float dx = (float)x - (float)px, dy = (float)y - (float)py;
         return (double)(dx * dx + dy * dy) < md2;
     };
+    auto too_close = [&](int x, int y, unsigned p) { return too_close_xy(x, y, (int)(p & 0xffff), (int)(p >> 16)); };
     if (tid == 0) s_total = 0;
+    if (LG) {
+        const int cells = a.gw * a.gh;
+        for (int q = tid; q < cells; q += CH) g_cnt[q] = 0;
+        for (int q = tid; q < 2 * cells; q += CH) ((unsigned *)g_pts)[q] = 0xFFFFFFFFu;
+    }
     __syncthreads();
     unsigned long long next_key = tid < n ? a.keys[tid] : 0ull; // a chunk's keys are fetched one chunk ahead
     for (int base = 0; base < n; base += CH) {
@@ -514,10 +598,10 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         if (total0 >= a.limit) break;
         const unsigned long long my_key = next_key;
         if (base + CH + tid < n) next_key = a.keys[base + CH + tid];
-        // What the previous chunk stored into the grid is read here by other waves of the same workgroup: they
-        // run on one CU and share its L1, so workgroup scope orders it (a wider scope would write back and
-        // invalidate the XCD's whole L2 twice per chunk, under every other frame of a batch).
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // What the previous chunk stored into a grid in global memory is read here by other waves of the same
+        // workgroup: they run on one CU and share its L1, so workgroup scope orders it (a wider scope would write back
+        // and invalidate the XCD's whole L2 twice per chunk, under every other frame of a batch).
+        if (!LG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (int q = tid; q < HT; q += CH) ht_key[q] = 0u;
         // (1) against the grid
         const int i = base + tid;
@@ -529,16 +613,34 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
             const unsigned idx = (unsigned)key;
             y = idx / a.w; x = idx - y * a.w;
             xc = x / a.cell; yc = y / a.cell;
-            uint4 c[9];
-#pragma unroll
-            for (int q = 0; q < 9; q++) { // cells off the grid are read as their clamped neighbour: a harmless repeat
-                const int cx = min(max(xc + q % 3 - 1, 0), a.gw - 1), cy = min(max(yc + q / 3 - 1, 0), a.gh - 1);
-                c[q] = a.cell_pts[cy * a.gw + cx];
-            }
             bool hit = false;
+            if (LG) {
+                uint2 c[9];
+                int ox[9], oy[9];
 #pragma unroll
-            for (int q = 0; q < 9; q++)
-                hit = hit || too_close(x, y, c[q].x) || too_close(x, y, c[q].y) || too_close(x, y, c[q].z) || too_close(x, y, c[q].w);
+                for (int q = 0; q < 9; q++) { // cells off the grid are read as their clamped neighbour: a harmless repeat
+                    const int cx = min(max(xc + q % 3 - 1, 0), a.gw - 1), cy = min(max(yc + q / 3 - 1, 0), a.gh - 1);
+                    c[q] = *(const uint2 *)(g_pts + 4 * (cy * a.gw + cx));
+                    ox[q] = cx * a.cell; oy[q] = cy * a.cell;
+                }
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const unsigned v[4] = {c[q].x & 0xffffu, c[q].x >> 16, c[q].y & 0xffffu, c[q].y >> 16};
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        hit = hit || (v[k] != 0xffffu && too_close_xy(x, y, ox[q] + (int)(v[k] & 0xff), oy[q] + (int)(v[k] >> 8)));
+                }
+            } else {
+                uint4 c[9];
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const int cx = min(max(xc + q % 3 - 1, 0), a.gw - 1), cy = min(max(yc + q / 3 - 1, 0), a.gh - 1);
+                    c[q] = a.cell_pts[cy * a.gw + cx];
+                }
+#pragma unroll
+                for (int q = 0; q < 9; q++)
+                    hit = hit || too_close(x, y, c[q].x) || too_close(x, y, c[q].y) || too_close(x, y, c[q].z) || too_close(x, y, c[q].w);
+            }
             surv = !hit;
         }
         // (2) survivors in rank order
@@ -622,13 +724,20 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                 const int mx = s_x[tid], my = s_y[tid];
                 a.xy[2 * pos] = (float)mx; a.xy[2 * pos + 1] = (float)my;
                 a.resp[pos] = ord2f((unsigned)(s_key[tid] >> 32));
-                const int ci = (my / a.cell) * a.gw + (mx / a.cell);
-                const int slot = atomicAdd(&a.cell_cnt[ci], 1);
-                if (slot < 4) ((unsigned *)&a.cell_pts[ci])[slot] = (unsigned)mx | ((unsigned)my << 16);
-                else *a.overflow = 2; // cannot happen for cell = round(min_dist); reported instead of dropped
+                const int cxi = mx / a.cell, cyi = my / a.cell;
+                const int ci = cyi * a.gw + cxi;
+                if (LG) {
+                    const int slot = atomicAdd(&g_cnt[ci], 1);
+                    if (slot < 4) g_pts[4 * ci + slot] = (unsigned short)((mx - cxi * a.cell) | ((my - cyi * a.cell) << 8));
+                    else *a.overflow = 2;
+                } else {
+                    const int slot = atomicAdd(&a.cell_cnt[ci], 1);
+                    if (slot < 4) ((unsigned *)&a.cell_pts[ci])[slot] = (unsigned)mx | ((unsigned)my << 16);
+                    else *a.overflow = 2; // cannot happen for cell = round(min_dist); reported instead of dropped
+                }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (!LG) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
     }
     if (tid == 0) *a.count = s_total;
@@ -781,6 +890,31 @@ static int sort_keys(ktlvo_ctx *ctx, unsigned long long *d_keys, size_t np2, int
     return KTLVO_OK;
 }
 
+// Kernels that ask for more than 64 KiB of dynamic LDS have to be told so once per device.
+// (bytes: the most the kernel will be launched with; together with its static arrays it must fit the 160 KiB of a compute unit)
+template <class K>
+static int allow_big_lds(ktlvo_ctx *ctx, K kernel, size_t bytes, bool &done) {
+    if (done) return KTLVO_OK;
+    KTLVO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done = true;
+    return KTLVO_OK;
+}
+// The greedy pass over n_rois sorted key lists, the grid in LDS when it fits (the cells in global memory are then not
+// used and need not be cleared).
+static bool select_uses_lds_grid(const SelLargeArgs &a) { return grid_fits_lds(a.cell, a.gw, a.gh); }
+static int launch_select_large(ktlvo_ctx *ctx, const SelLargeArgs &a, int n_rois) {
+    if (select_uses_lds_grid(a)) {
+        int rc = allow_big_lds(ctx, corner_select_large<true>, SEL_LDS_GRID_MAX, ctx->big_lds_select);
+        if (rc != KTLVO_OK) return rc;
+        hipLaunchKernelGGL(corner_select_large<true>, dim3((unsigned)n_rois), dim3(CH), (size_t)a.gw * a.gh * SEL_LDS_PER_CELL,
+                           ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(corner_select_large<false>, dim3((unsigned)n_rois), dim3(CH), 0, ctx->stream, a);
+    }
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
 // Sort + greedy pass of one large ROI on the device.  n_sup = the ROI's candidate count (already on the host).
 static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, const ktlvo_gftt_params *p,
                         const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap) {
@@ -803,8 +937,9 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     int *d_n = (int *)(b + o_n);
     // keys, counter and the cells' counts cleared in one go (the sort runs over all np2 keys; zeros sort last);
     // empty places of the cells hold a far-away point
-    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc + (dist ? up((size_t)gw * gh * 4) : 0), ctx->stream));
-    if (dist) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)gw * gh * 16, ctx->stream));
+    const bool global_grid = dist && !grid_fits_lds(cell, gw, gh);
+    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc + (global_grid ? up((size_t)gw * gh * 4) : 0), ctx->stream));
+    if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)gw * gh * 16, ctx->stream));
     const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
     hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
                        p->quality, d_keys, d_n, (size_t)0, (size_t)0);
@@ -822,7 +957,8 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
         a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
         a.xy = d_xy; a.resp = d_resp; a.count = d_count; a.overflow = s.d_overflow;
         a.keys_stride = a.cells_stride = a.out_stride = 0;
-        hipLaunchKernelGGL(corner_select_large, dim3(1), dim3(CH), 0, ctx->stream, a);
+        rc = launch_select_large(ctx, a, 1);
+        if (rc != KTLVO_OK) return rc;
     }
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
@@ -832,9 +968,8 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
 // goodFeaturesToTrack on the same ROI of n_frames slots with the launches of ONE detection: every kernel of the
 // whole-frame path takes a frame index from its grid.  A single frame leaves the GPU mostly idle (its greedy pass is
 // one workgroup, its sort a few dozen); a batch fills it, and the cost per frame drops by two orders of magnitude.
-// Per frame the result is ktlvo_detect_gftt's for that slot and ROI (same kernels, same keys; the sort runs over the
-// batch's largest candidate count instead of the frame's own, which does not change the order of unique keys).
-// Outputs are device arrays [n_frames][cap]; the host waits once, for the candidate counts that size the sort.
+// Per frame the result is ktlvo_detect_gftt's for that slot and ROI (same candidates, same unique keys in the same
+// order, same greedy pass).  Outputs are device arrays [n_frames][cap]; the call returns once they are complete.
 static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi &roi, const ktlvo_gftt_params *p,
                              float *d_xy, float *d_resp, int *d_counts, int cap) {
     const size_t area = (size_t)roi.w * roi.h;
@@ -846,18 +981,65 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     const size_t o_slots = up(corner_scratch_bytes(n_frames, area * n_frames));
     int rc = ensure_misc(ctx, o_slots + up(4 * (size_t)n_frames));
     if (rc != KTLVO_OK) return rc;
-    rc = ensure_pin(ctx, 8 * (size_t)n_frames + 8);
+    rc = ensure_pin(ctx, 8 * (size_t)n_frames + 16);
     if (rc != KTLVO_OK) return rc;
     CornerScratch s;
     corner_scratch_carve(ctx->d_misc, n_frames, area * n_frames, s);
     int *d_roi_slots = (int *)((char *)ctx->d_misc + o_slots);
-    int *h_slots = (int *)ctx->h_pin, *h_cnt = h_slots + n_frames, *h_ovf = h_cnt + n_frames;
+    int *h_slots = (int *)ctx->h_pin, *h_cnt = h_slots + n_frames, *h_ovf = h_cnt + n_frames, *h_many = h_ovf + 1;
     for (int f = 0; f < n_frames; f++) h_slots[f] = slots[f];
     KTLVO_HIP(ctx, hipMemcpyAsync(d_roi_slots, h_slots, 4 * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
     rc = corner_scratch_setup(ctx, rois.data(), n_frames, s);
     if (rc != KTLVO_OK) return rc;
     rc = run_candidates(ctx, -1, n_frames, roi.w, roi.h, p->use_harris, p->harris_k, s, nullptr, true, d_roi_slots);
     if (rc != KTLVO_OK) return rc;
+    const bool dist = p->min_dist >= 1;
+    const int cell = dist ? (int)lrint(p->min_dist) : 1;
+    const int gw = dist ? (roi.w + cell - 1) / cell : 0, gh = dist ? (roi.h + cell - 1) / cell : 0;
+    const size_t cells = (size_t)gw * gh;
+    const bool global_grid = dist && !grid_fits_lds(cell, gw, gh);
+    const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
+    SelLargeArgs a;
+    a.w = roi.w; a.h = roi.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh; a.limit = limit;
+    a.xy = d_xy; a.resp = d_resp; a.count = d_counts; a.overflow = s.d_overflow;
+    a.cells_stride = cells; a.out_stride = (size_t)cap;
+
+    if (ctx->frames_lds_sort) {
+        // Every frame filtered and sorted by one workgroup in LDS, then the greedy pass: nothing is sized on the host, so
+        // the whole detection is queued in one go and the host waits once, at the end, to learn whether a frame had more
+        // keys than the LDS sort holds; then, and only then, the global path below does the batch again.
+        const size_t o_n = up((size_t)SORT_CAP * 8 * n_frames), o_flag = o_n + up(4 * (size_t)n_frames), o_cc = o_flag + 256;
+        const size_t o_cp = o_cc + (global_grid ? up(cells * 4 * n_frames) : 0);
+        const size_t total = o_cp + (global_grid ? up(cells * 16 * n_frames) : 0);
+        rc = ensure_aux(ctx, total);
+        if (rc != KTLVO_OK) return rc;
+        rc = allow_big_lds(ctx, corner_sort_frames, (size_t)SORT_CAP * 8, ctx->big_lds_sort);
+        if (rc != KTLVO_OK) return rc;
+        char *b = (char *)ctx->d_aux;
+        unsigned long long *d_keys = (unsigned long long *)b;
+        int *d_n = (int *)(b + o_n), *d_many = (int *)(b + o_flag);
+        KTLVO_HIP(ctx, hipMemsetAsync(b + o_flag, 0, o_cp - o_flag, ctx->stream)); // the flag and, if used, the cells' counts
+        if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+        hipLaunchKernelGGL(corner_sort_frames, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_CAP * 8, ctx->stream, s.d_cand,
+                           s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, (size_t)SORT_CAP, d_many);
+        KTLVO_HIP(ctx, hipGetLastError());
+        if (!dist) {
+            hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys,
+                               d_n, roi.w, limit, d_xy, d_resp, d_counts, (size_t)SORT_CAP, (size_t)cap);
+            KTLVO_HIP(ctx, hipGetLastError());
+        } else {
+            a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = (size_t)SORT_CAP;
+            a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
+            rc = launch_select_large(ctx, a, n_frames);
+            if (rc != KTLVO_OK) return rc;
+        }
+        KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(h_many, d_many, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!*h_many) return KTLVO_OK;
+    }
+
+    // Global path: the sort runs in global memory over the batch's largest candidate count, which the host fetches first.
     KTLVO_HIP(ctx, hipMemcpyAsync(h_cnt, s.d_cnt, 4 * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int n_sup = 0;
@@ -869,10 +1051,6 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     }
     size_t np2 = 1;
     while (np2 < (size_t)n_sup) np2 <<= 1;
-    const bool dist = p->min_dist >= 1;
-    const int cell = dist ? (int)lrint(p->min_dist) : 1;
-    const int gw = dist ? (roi.w + cell - 1) / cell : 0, gh = dist ? (roi.h + cell - 1) / cell : 0;
-    const size_t cells = (size_t)gw * gh;
     const size_t o_keys = 0, o_n = o_keys + up(np2 * 8 * n_frames), o_cc = o_n + up(4 * (size_t)n_frames);
     const size_t o_cp = o_cc + up(cells * 4 * n_frames), total = o_cp + up(cells * 16 * n_frames);
     rc = ensure_aux(ctx, total);
@@ -880,27 +1058,24 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cp, ctx->stream)); // keys, counters, the cells' counts
-    if (dist) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, global_grid ? o_cp : o_cc, ctx->stream)); // keys, counters, the cells' counts
+    if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
     const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
     hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
                        p->quality, d_keys, d_n, area, np2);
     KTLVO_HIP(ctx, hipGetLastError());
     rc = sort_keys(ctx, d_keys, np2, n_frames, d_n);
     if (rc != KTLVO_OK) return rc;
-    const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     if (!dist) {
         hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys, d_n,
                            roi.w, limit, d_xy, d_resp, d_counts, np2, (size_t)cap);
+        KTLVO_HIP(ctx, hipGetLastError());
     } else {
-        SelLargeArgs a;
-        a.keys = d_keys; a.n_ptr = d_n; a.w = roi.w; a.h = roi.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh;
-        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
-        a.xy = d_xy; a.resp = d_resp; a.count = d_counts; a.overflow = s.d_overflow;
-        a.keys_stride = np2; a.cells_stride = cells; a.out_stride = (size_t)cap;
-        hipLaunchKernelGGL(corner_select_large, dim3((unsigned)n_frames), dim3(CH), 0, ctx->stream, a);
+        a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = np2;
+        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
+        rc = launch_select_large(ctx, a, n_frames);
+        if (rc != KTLVO_OK) return rc;
     }
-    KTLVO_HIP(ctx, hipGetLastError());
     // the overflow flag lands in pinned memory behind the counts' mirror; a caller that waits for the stream reads it there
     KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     return KTLVO_OK;

@@ -618,6 +618,42 @@ def test_batched_detection_equals_per_frame_detection(make_ctx, klib):
     assert ei.value.status == klib.ERR_STATE
 
 
+def test_batched_detection_lds_sort_equals_global_sort(make_ctx, klib):
+    """The batched detector filters and sorts each frame in LDS by one workgroup and keeps the greedy pass's cell grid
+    in LDS when it fits; a frame with more keys above its threshold than the LDS sort holds (16384) sends the whole
+    batch through the global sort instead.  Both routes must give what a context created with
+    KTLVO_FRAMES_GLOBAL_SORT=1 gives, and what per-frame detection gives: KITTI-sized frames (12,000 keys each; the
+    LDS route), the same batch with a white-noise frame in it (50,000 keys; the fallback), a minimum distance whose
+    grid does not fit LDS, and no minimum distance at all."""
+    from slam_amd.synth import texture_image
+    W, H = 1241, 376
+    rng = np.random.default_rng(91)
+    imgs = [texture_image(W, H, seed=70 + i, noise=True) for i in range(3)]
+    imgs.append(np.full((H, W), 77, np.uint8))
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    fast = make_ctx(width=W, height=H, num_slots=5)
+    os.environ["KTLVO_FRAMES_GLOBAL_SORT"] = "1"
+    try:
+        slow = make_ctx(width=W, height=H, num_slots=5)
+    finally:
+        del os.environ["KTLVO_FRAMES_GLOBAL_SORT"]
+    for ctx in (fast, slow):
+        ctx.upload_images([0, 1, 2, 3, 4], np.stack(imgs + [noise]))
+    for params in (klib.gftt_params(2000, 0.01, 10.0, 3, 0, 0.0), klib.gftt_params(2000, 0.01, 9.0, 3, 0, 0.0),
+                   klib.gftt_params(4000, 0.003, 3.0, 3, 0, 0.0), klib.gftt_params(5000, 0.01, 0.0, 3, 0, 0.0),
+                   klib.gftt_params(300, 0.05, 40.0, 3, 1, 0.04)):
+        for order in ([0, 1, 2, 3, 1], [2, 4, 0, 3]):                           # without / with the noise frame
+            a = fast.detect_gftt_frames(order, params)
+            b = slow.detect_gftt_frames(order, params)
+            for s_, (xa, ra), (xb, rb) in zip(order, a, b):
+                assert np.array_equal(xa, xb) and np.array_equal(ra, rb), (s_, len(xa), len(xb))
+        for s_, (xa, ra) in zip([0, 1, 2, 3, 1], fast.detect_gftt_frames([0, 1, 2, 3, 1], params)):
+            (rxy, rresp), = fast.detect_gftt(s_, [(0, 0, W, H)], params)
+            assert np.array_equal(xa, rxy) and np.array_equal(ra, rresp), (s_, len(xa), len(rxy))
+    got = fast.detect_gftt_frames([0, 3], klib.gftt_params(2000, 0.01, 10.0, 3, 0, 0.0))
+    assert len(got[0][0]) == 2000 and len(got[1][0]) == 0
+
+
 def test_batched_upload_equals_per_frame_upload(make_ctx):
     """ktlvo_upload_images (one DMA, one ingest launch) fills the slots exactly as n ktlvo_upload_image calls do,
     from pageable and from pinned memory, into slots given in any order."""
