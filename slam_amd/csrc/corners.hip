@@ -460,18 +460,97 @@ __global__ __launch_bounds__(256) void bitonic_global_step(unsigned long long *k
     if (desc ? x < y : x > y) { keys[i] = y; keys[p] = x; }
 }
 
-// Filter and sort of one frame's candidates by ONE workgroup, wholly in LDS (blockIdx.x = frame of a batch): the keys
-// above the frame's threshold are compacted into LDS as they are read, padded with zeros to a power of two and sorted
-// descending by the same bitonic network; the first out_cnt keys go to out[].  For frames of up to SORT_CAP keys above
-// the threshold (128 KiB of LDS) this replaces cand_filter, the clearing of the key buffer and the dozen launches of
-// the global sort, and nothing has to be sized on the host, so the host need not wait for the candidate counts.  A
-// frame with more keys is left alone: its count is set to zero and *too_many is raised, and the caller runs the global
-// path instead.
+// Filter and sort of one frame's candidates by ONE workgroup, wholly in LDS and registers (blockIdx.x = frame of a
+// batch): the keys above the frame's threshold are compacted into LDS as they are read, padded with zeros to a power
+// of two and sorted descending by the same bitonic network; the first out_cnt keys go to out[].  For frames of up to
+// SORT_CAP keys above the threshold this replaces cand_filter, the clearing of the key buffer and the dozen launches
+// of the global sort, and nothing has to be sized on the host, so the host need not wait for the candidate counts.
+// A frame with more keys is left alone: its count is set to zero and *too_many is raised, and the caller runs the
+// global path instead.
+//
+// The network runs on registers: each of the 1024 threads holds 16 keys, namely those whose 14-bit index agrees with
+// the thread's in all but a window of four bits [LO, LO + 3] (the register number).  A compare-exchange at distance
+// 2^b with b inside the window is then between two registers of one thread and needs neither LDS nor a barrier; for
+// bits outside it the keys are re-dealt through LDS into another window.  Stage S of the network (runs of 2^S keys,
+// distances 2^(S-1) ... 1) takes the windows [10,13], [8,11], [4,7], [0,3] as far as it needs them, highest first, so
+// the whole sort of 16384 keys costs 28 passes through LDS instead of the 105 of a step-by-step network.  A key's
+// place in LDS is its index plus index / 16: with the gap, the sixteen keys a thread owns in window 0 (consecutive
+// ones) do not fall on the banks of its neighbours' keys.
 constexpr int SORT_CAP = 16384;
+constexpr int SORT_LDS_KEYS = SORT_CAP + SORT_CAP / 16;
+typedef unsigned long long u64;
+__device__ __forceinline__ int sort_place(int i) { return i + (i >> 4); }
+template <int LO>
+__device__ __forceinline__ int sort_index(int t, int r) { return ((t >> LO) << (LO + 4)) | (r << LO) | (t & ((1 << LO) - 1)); }
+template <int LO>
+__device__ __forceinline__ void sort_load(const u64 *sk, int t, int np2, u64 (&k)[16]) {
+    if (sort_index<LO>(t, 0) >= np2) return; // this thread's sixteen keys all lie in the zero padding beyond np2
+#pragma unroll
+    for (int r = 0; r < 16; r++) k[r] = sk[sort_place(sort_index<LO>(t, r))];
+}
+template <int LO>
+__device__ __forceinline__ void sort_store(u64 *sk, int t, int np2, const u64 (&k)[16]) {
+    if (sort_index<LO>(t, 0) >= np2) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) sk[sort_place(sort_index<LO>(t, r))] = k[r];
+}
+// the compare-exchanges of stage S for the bits BHI ... LO (all inside the window)
+template <int LO, int S, int BHI>
+__device__ __forceinline__ void sort_steps(int t, int np2, u64 (&k)[16]) {
+    if (sort_index<LO>(t, 0) >= np2) return;
+    // a run of 2^S keys is sorted descending if bit S of its keys' index is clear: inside the window that is a
+    // property of the register number, above it of the thread
+    const bool asc_t = (sort_index<LO>(t, 0) >> S) & 1;
+#pragma unroll
+    for (int b = BHI; b >= LO; --b) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (r & (1 << (b - LO))) continue;
+            bool asc = asc_t;
+            if constexpr (S <= LO + 3) asc = ((r >> (S - LO)) & 1) != 0;
+            u64 &x = k[r], &y = k[r | (1 << (b - LO))];
+            const bool sw = asc ? x > y : x < y;
+            const u64 nx = sw ? y : x, ny = sw ? x : y;
+            x = nx; y = ny;
+        }
+    }
+}
+template <int FROM, int TO>
+__device__ __forceinline__ void sort_redeal(u64 *sk, int t, int np2, u64 (&k)[16]) {
+    __syncthreads(); // every thread has read what the previous re-deal stored
+    sort_store<FROM>(sk, t, np2, k);
+    __syncthreads();
+    sort_load<TO>(sk, t, np2, k);
+}
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+// stage S, entered and left with the keys dealt for window 0
+template <int S>
+__device__ __forceinline__ void sort_stage(u64 *sk, int t, int np2, u64 (&k)[16]) {
+    if constexpr (S >= 13) {
+        sort_redeal<0, 10>(sk, t, np2, k);
+        sort_steps<10, S, S - 1>(t, np2, k);
+        sort_redeal<10, 8>(sk, t, np2, k);
+        sort_steps<8, S, 9>(t, np2, k);
+        sort_redeal<8, 4>(sk, t, np2, k);
+        sort_steps<4, S, 7>(t, np2, k);
+        sort_redeal<4, 0>(sk, t, np2, k);
+    } else if constexpr (S >= 9) {
+        sort_redeal<0, 8>(sk, t, np2, k);
+        sort_steps<8, S, cmin(S - 1, 11)>(t, np2, k);
+        sort_redeal<8, 4>(sk, t, np2, k);
+        sort_steps<4, S, 7>(t, np2, k);
+        sort_redeal<4, 0>(sk, t, np2, k);
+    } else if constexpr (S >= 5) {
+        sort_redeal<0, 4>(sk, t, np2, k);
+        sort_steps<4, S, cmin(S - 1, 7)>(t, np2, k);
+        sort_redeal<4, 0>(sk, t, np2, k);
+    }
+    sort_steps<0, S, cmin(S - 1, 3)>(t, np2, k);
+}
 __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long long *cand, const int *cand_cnt,
                                                            const unsigned *roi_max, double quality, unsigned long long *out,
                                                            int *out_cnt, size_t cand_stride, size_t out_stride, int *too_many) {
-    extern __shared__ unsigned long long sk[]; // SORT_CAP keys
+    extern __shared__ u64 sk[]; // SORT_LDS_KEYS keys
     __shared__ int s_n;
     cand += blockIdx.x * cand_stride; out += blockIdx.x * out_stride;
     const int n = cand_cnt[blockIdx.x];
@@ -481,19 +560,19 @@ __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long l
     __syncthreads();
     for (int base = 0; base < n; base += 1024) { // uniform trip count
         const int i = base + tid;
-        unsigned long long key = 0;
+        u64 key = 0;
         bool keep = false;
         if (i < n) {
             key = cand[i];
             keep = ord2f((unsigned)(key >> 32)) > thr;
         }
-        const unsigned long long vote = __ballot(keep);
+        const u64 vote = __ballot(keep);
         int woff = 0;
         if (lane == 0 && vote) woff = atomicAdd(&s_n, __popcll(vote));
         woff = __builtin_amdgcn_readfirstlane(woff);
         if (keep) {
             const int p = woff + __popcll(vote & ((1ull << lane) - 1ull));
-            if (p < SORT_CAP) sk[p] = key;
+            if (p < SORT_CAP) sk[sort_place(p)] = key;
         }
     }
     __syncthreads();
@@ -502,23 +581,32 @@ __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long l
         if (tid == 0) { out_cnt[blockIdx.x] = 0; *too_many = 1; }
         return;
     }
-    int np2 = 2;
-    while (np2 < m) np2 <<= 1;
-    for (int i = m + tid; i < np2; i += 1024) sk[i] = 0ull;
+    int np2 = 16, lg = 4; // at least one thread's worth
+    while (np2 < m) { np2 <<= 1; lg++; }
+    for (int i = m + tid; i < np2; i += 1024) sk[sort_place(i)] = 0ull;
     __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            // thread t owns the pairs (i, i | j), i = t' with a zero bit inserted at position log2(j), t' = t, t + 1024, ...
-#pragma unroll 4
-            for (int t = tid; t < (np2 >> 1); t += 1024) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-                const unsigned long long x = sk[i], y = sk[p];
-                const bool desc = (i & k) == 0;
-                if (desc ? x < y : x > y) { sk[i] = y; sk[p] = x; }
-            }
-            __syncthreads();
-        }
-    for (int i = tid; i < m; i += 1024) out[i] = sk[i];
+    u64 k[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) k[r] = 0ull;
+    sort_load<0>(sk, tid, np2, k);
+    sort_stage<1>(sk, tid, np2, k);
+    sort_stage<2>(sk, tid, np2, k);
+    sort_stage<3>(sk, tid, np2, k);
+    sort_stage<4>(sk, tid, np2, k);
+    if (lg >= 5) sort_stage<5>(sk, tid, np2, k);
+    if (lg >= 6) sort_stage<6>(sk, tid, np2, k);
+    if (lg >= 7) sort_stage<7>(sk, tid, np2, k);
+    if (lg >= 8) sort_stage<8>(sk, tid, np2, k);
+    if (lg >= 9) sort_stage<9>(sk, tid, np2, k);
+    if (lg >= 10) sort_stage<10>(sk, tid, np2, k);
+    if (lg >= 11) sort_stage<11>(sk, tid, np2, k);
+    if (lg >= 12) sort_stage<12>(sk, tid, np2, k);
+    if (lg >= 13) sort_stage<13>(sk, tid, np2, k);
+    if (lg >= 14) sort_stage<14>(sk, tid, np2, k);
+    // window 0: thread t holds keys 16 t ... 16 t + 15 of the sorted list
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        if (16 * tid + r < m) out[16 * tid + r] = k[r];
     if (tid == 0) out_cnt[blockIdx.x] = m;
 }
 
@@ -570,7 +658,7 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     unsigned short *const g_pts = (unsigned short *)(dyn_lds + 4 * (size_t)a.gw * a.gh); // ... then gw * gh * 4 places
     __shared__ unsigned long long s_key[CH];
     __shared__ int s_x[CH], s_y[CH];
-    __shared__ unsigned conf[CH][CH / 32];
+    __shared__ __attribute__((aligned(16))) unsigned conf[CH][CH / 32];
     __shared__ unsigned ht_key[HT]; // cell index + 1, 0 = empty
     __shared__ unsigned short ht_val[HT];
     __shared__ unsigned accm[CH / 32], rejm[CH / 32];
@@ -669,24 +757,34 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         if (tid < S) {
             const int mx = s_x[tid], my = s_y[tid];
             const int mxc = mx / a.cell, myc = my / a.cell;
-            for (int wq = 0; wq < CH / 32; wq++) conf[tid][wq] = 0u;
+            for (int wq = 0; wq < CH / 128; wq++) ((uint4 *)conf[tid])[wq] = uint4{0u, 0u, 0u, 0u};
             bool any = false;
-            for (int cy = max(myc - 1, 0); cy <= min(myc + 1, a.gh - 1); cy++)
-                for (int cx = max(mxc - 1, 0); cx <= min(mxc + 1, a.gw - 1); cx++) {
-                    const unsigned ck = (unsigned)(cy * a.gw + cx) + 1u;
-                    for (unsigned hsh = (ck * 2654435761u) >> 21;; hsh = (hsh + 1) & (HT - 1)) {
-                        const unsigned kk = ht_key[hsh];
-                        if (kk == 0u) break;
-                        if (kk != ck) continue;
-                        const int q = ht_val[hsh];
-                        if (q >= tid) continue;
-                        const float dx = (float)(mx - s_x[q]), dy = (float)(my - s_y[q]);
-                        if (fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2) {
-                            conf[tid][q >> 5] |= 1u << (q & 31);
-                            any = true;
-                        }
+            // the nine cells' first probes go out together: most cells hold no survivor of this chunk, and a probe
+            // chain per cell, one after the other, is nine LDS round trips where this is one
+            unsigned ck9[9], h9[9], k9[9];
+#pragma unroll
+            for (int c9 = 0; c9 < 9; c9++) {
+                const int cx = mxc + c9 % 3 - 1, cy = myc + c9 / 3 - 1;
+                const bool in = cx >= 0 && cy >= 0 && cx < a.gw && cy < a.gh;
+                ck9[c9] = in ? (unsigned)(cy * a.gw + cx) + 1u : 0u;
+                h9[c9] = (ck9[c9] * 2654435761u) >> 21;
+                k9[c9] = in ? ht_key[h9[c9]] : 0u;
+            }
+#pragma unroll
+            for (int c9 = 0; c9 < 9; c9++) {
+                const unsigned ck = ck9[c9];
+                unsigned kk = k9[c9];
+                for (unsigned hsh = h9[c9]; kk != 0u; hsh = (hsh + 1) & (HT - 1), kk = ht_key[hsh]) {
+                    if (kk != ck) continue;
+                    const int q = ht_val[hsh];
+                    if (q >= tid) continue;
+                    const float dx = (float)(mx - s_x[q]), dy = (float)(my - s_y[q]);
+                    if (fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2) {
+                        conf[tid][q >> 5] |= 1u << (q & 31);
+                        any = true;
                     }
                 }
+            }
             state = any ? 0 : 1;
         }
         // (3) rounds (none when no survivor of the chunk has a predecessor within reach, the usual case)
@@ -1013,14 +1111,14 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         const size_t total = o_cp + (global_grid ? up(cells * 16 * n_frames) : 0);
         rc = ensure_aux(ctx, total);
         if (rc != KTLVO_OK) return rc;
-        rc = allow_big_lds(ctx, corner_sort_frames, (size_t)SORT_CAP * 8, ctx->big_lds_sort);
+        rc = allow_big_lds(ctx, corner_sort_frames, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
         if (rc != KTLVO_OK) return rc;
         char *b = (char *)ctx->d_aux;
         unsigned long long *d_keys = (unsigned long long *)b;
         int *d_n = (int *)(b + o_n), *d_many = (int *)(b + o_flag);
         KTLVO_HIP(ctx, hipMemsetAsync(b + o_flag, 0, o_cp - o_flag, ctx->stream)); // the flag and, if used, the cells' counts
         if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
-        hipLaunchKernelGGL(corner_sort_frames, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_CAP * 8, ctx->stream, s.d_cand,
+        hipLaunchKernelGGL(corner_sort_frames, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand,
                            s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, (size_t)SORT_CAP, d_many);
         KTLVO_HIP(ctx, hipGetLastError());
         if (!dist) {
