@@ -6,6 +6,9 @@
 //                         image: image, covariance and response tiles live in LDS, only candidate keys
 //                         (value, raster index) and the ROI maximum go to global memory.  The response
 //                         map is never written (ktlvo_corner_response, a test hook, asks for it).
+//   corner_candidates_wave  the same pass for larger ROIs (whole frames) on registers: a wave walks down a strip of
+//                         58 columns, every stage's last rows in registers, neighbours by DPP wave shifts; no LDS
+//                         tiles, no barriers; same operations in the same order, half the instructions
 //   corner_select         per ROI of at most 4096 pixels: bitonic sort of the keys in LDS
 //                         (std::sort(greaterThanPtr)), threshold at quality * max, then the greedy
 //                         minimum-distance pass over a cell grid in LDS
@@ -240,6 +243,168 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
         const int place = block_base + wave_cnt[wave][q] + __popcll(votes[q] & ((1ull << lane) - 1ull));
         cand[R.off + place] = ((unsigned long long)f2ord(vals[q]) << 32) | (unsigned)((ty0 + oy) * R.w + (tx0 + ox));
     }
+}
+
+// ---- the same pass for large ROIs (whole frames), on registers ------------------------------------------------------
+// corner_candidates pays for its LDS tiles: every stage writes a tile, waits for the workgroup and reads each value
+// back three times, and two thirds of its instructions are that traffic and its addressing.  Here a WAVE owns a strip
+// of 58 columns and a band of rows and walks down it one image row at a time: lane l holds column x0 - 3 + l, every
+// stage keeps the two or three rows it still needs in registers, and the horizontal neighbours come from the
+// neighbouring lanes by DPP wave shifts (no LDS, no barrier).  The three columns at each end of the wave are halo:
+// lanes 1..62 have valid covariance terms, 2..61 valid responses, 3..60 are the strip's own pixels.  Per pixel the
+// float and double operations, and their order, are corner_candidates' own, so responses, ROI maximum and candidate
+// keys are identical (the candidates' order in the list differs, which the sort undoes: keys are unique).
+// Candidates are gathered in a per-wave LDS buffer and go out with one returning atomic per flush.
+// For ROIs of at least 8 x 8 pixels (mirror rows and columns 1 and n - 2 exist and are distinct from the edges).
+constexpr int CW_COLS = 58;   // own columns of a wave
+constexpr int CW_BUF = 448;   // candidate keys a wave holds before it flushes
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// v with lane `to` replaced by lane `from`'s value (both wave-uniform)
+__device__ __forceinline__ float copy_lane(float v, int from, int to, int lane) {
+    const float src = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from));
+    return lane == to ? src : v;
+}
+constexpr int DPP_FROM_RIGHT = 0x130; // wave_shl:1, lane l reads lane l + 1
+constexpr int DPP_FROM_LEFT = 0x138;  // wave_shr:1, lane l reads lane l - 1
+struct CwGrid {
+    int strips, bands, band_rows; // per ROI: strips x bands wave tasks, band_rows output rows per band
+};
+template <bool HARRIS>
+__global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *slots, int slot, const RoiDev *rois, float s1, float s2,
+                                                              double k, float *resp_out, unsigned *roi_max,
+                                                              unsigned long long *cand, int *cand_cnt, CwGrid g, int n_roi,
+                                                              const int *roi_slots) {
+    __shared__ unsigned long long buf_all[4][CW_BUF + 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long *const buf = buf_all[wave];
+    // wave tasks are dealt like corner_candidates' tiles: the workgroups of one XCD walk a contiguous run of tasks
+    const int per_roi = g.strips * g.bands, n_tasks = per_roi * n_roi;
+    const int n_groups = (n_tasks + 3) >> 2, per_xcd = (n_groups + 7) >> 3;
+    const int group = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int task = group * 4 + wave;
+    if (group >= n_groups || task >= n_tasks) return;
+    const int roi_id = task / per_roi, tr = task - roi_id * per_roi;
+    const int band = tr / g.strips, strip = tr - band * g.strips;
+    const RoiDev R = rois[roi_id];
+    const int W = R.w, H = R.h;
+    const int x0 = strip * CW_COLS, y0 = band * g.band_rows, y1 = min(y0 + g.band_rows, H);
+    if (x0 >= W || y0 >= H) return;
+    const LevelDesc L = slots[roi_slots ? roi_slots[roi_id] : slot].lv[0];
+    typedef const __attribute__((address_space(1))) uint8_t *gsrc;
+    const int x = x0 - 3 + lane; // ROI-relative column of this lane
+    const gsrc col = (gsrc)L.origin + (ptrdiff_t)R.y * L.pitch + (R.x + x);
+    const bool in_cols = x >= 0 && x < W;                       // a response exists here
+    const bool own = lane >= 3 && lane <= 60 && x < W;          // this wave's own pixels
+    const bool cand_col = own && x >= 1 && x < W - 1;           // goodFeaturesToTrack scans the interior
+    // the box filter reflects at the ROI's edges: covariance column -1 is column 1, column W is column W - 2
+    const int lane_m1 = 2 - x0, lane_w = W - x0 + 3;            // lanes of columns -1 and W, if this strip holds them
+    const bool fix_left = lane_m1 >= 1, fix_right = lane_w <= 62;
+    const bool top = y0 == 0, bottom = y1 == H;
+    const int iy_first = top ? -1 : y0 - 3, iy_last = bottom ? H : y1 + 2;
+    const int n_iter = iy_last - iy_first + 1 + (bottom ? 1 : 0); // the bottom band's last step has no image row
+    const int yr_first = top ? 0 : y0 - 1;
+
+    float vmax = -INFINITY;
+    int n_buf = 0; // wave-uniform
+    auto flush = [&]() {
+        if (n_buf == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cand_cnt[roi_id], n_buf);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int i = lane; i < n_buf; i += 64) cand[R.off + base + i] = buf[i];
+        n_buf = 0;
+    };
+    // One image row.  (dA, dB, dC) are the Sobel row terms d of rows iy - 2, iy - 1, iy (dC written here), (qA, ., qC)
+    // the terms q; (sA, sB, sC) the box filter's row sums of covariance rows yc - 2, yc - 1, yc (sC written here);
+    // (mA, mB, mC) the three-wide maxima of response rows yr - 2, yr - 1, yr, and vB the responses of row yr - 1.
+    // The caller rotates the roles from step to step, so nothing is copied.
+    struct Sums { double a, b, c; }; // of cxx, cxy, cyy
+    auto step = [&](const int i, float &dA, float &dB, float &dC, float &qA, float &qC, Sums &sA, Sums &sB,
+                    Sums &sC, float &mA, float &mB, float &mC, float &vB, float &vC) __attribute__((always_inline)) {
+        const int iy = iy_first + i;
+        const bool virt = bottom && i == n_iter - 1;
+        const int yc = iy - 1;
+        if (!virt) {
+            const float a = (float)col[(ptrdiff_t)iy * L.pitch];
+            const float am = dpp_f<DPP_FROM_LEFT>(a), ap = dpp_f<DPP_FROM_RIGHT>(a);
+            dC = ap - am;
+            float q = s1 * am; q += s2 * a; q += s1 * ap;
+            qC = q;
+            if (i < 2) return;
+            const float dx = (dA + dC) * s1 + dB * s2;
+            const float dy = qC - qA;
+            float cxx = dx * dx, cxy = dx * dy, cyy = dy * dy;
+            if (fix_left) {
+                cxx = copy_lane(cxx, lane_m1 + 2, lane_m1, lane);
+                cxy = copy_lane(cxy, lane_m1 + 2, lane_m1, lane);
+                cyy = copy_lane(cyy, lane_m1 + 2, lane_m1, lane);
+            }
+            if (fix_right) {
+                cxx = copy_lane(cxx, lane_w - 2, lane_w, lane);
+                cxy = copy_lane(cxy, lane_w - 2, lane_w, lane);
+                cyy = copy_lane(cyy, lane_w - 2, lane_w, lane);
+            }
+            // cv::boxFilter sums float input in double, a row's three entries left to right
+            const double ca = (double)cxx, cb = (double)cxy, cc = (double)cyy;
+            sC.a = (dpp_d<DPP_FROM_LEFT>(ca) + ca) + dpp_d<DPP_FROM_RIGHT>(ca);
+            sC.b = (dpp_d<DPP_FROM_LEFT>(cb) + cb) + dpp_d<DPP_FROM_RIGHT>(cb);
+            sC.c = (dpp_d<DPP_FROM_LEFT>(cc) + cc) + dpp_d<DPP_FROM_RIGHT>(cc);
+            if (top && yc == 1) sA = sC; // covariance row -1 is row 1
+        } else {
+            sC = sA;                     // covariance row H is row H - 2
+        }
+        const int yr = yc - 1;
+        if (yr < yr_first) return;
+        // then down the column: (row yr - 1 + row yr) + row yr + 1
+        const float fa = (float)((sA.a + sB.a) + sC.a), fb = (float)((sA.b + sB.b) + sC.b), fc = (float)((sA.c + sB.c) + sC.c);
+        float r;
+        if (HARRIS) {
+            const float t = fa * fc - fb * fb;
+            r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
+        } else {
+            const float ha = fa * 0.5f, hc = fc * 0.5f;
+            r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
+        }
+        if (lane >= 2 && lane <= 61 && in_cols) vmax = fmaxf(vmax, r);
+        if (resp_out && own && yr >= y0 && yr < y1) resp_out[R.off + yr * W + x] = r;
+        r = in_cols ? r : -INFINITY;
+        vC = r;
+        mC = fmaxf(fmaxf(dpp_f<DPP_FROM_LEFT>(r), r), dpp_f<DPP_FROM_RIGHT>(r));
+        const int yo = yr - 1;
+        if (!cand || yo < y0 || yo < 1 || yo >= H - 1) return;
+        const float m = fmaxf(fmaxf(mA, mB), mC);
+        const bool keep = cand_col && vB > 0.f && vB == m;
+        const unsigned long long vote = __ballot(keep);
+        if (vote) {
+            if (keep) buf[n_buf + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)f2ord(vB) << 32) | (unsigned)(yo * W + x);
+            n_buf += __popcll(vote);
+            if (n_buf > CW_BUF) flush();
+        }
+    };
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+    Sums s0 = {0, 0, 0}, sb1 = {0, 0, 0}, sb2 = {0, 0, 0};
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, v0 = -INFINITY, v1 = -INFINITY, v2 = -INFINITY;
+    // roles rotate with period three: step i writes slot i mod 3 of every stage
+    for (int i = 0; i < n_iter; i += 3) {
+        step(i, d1, d2, d0, q1, q0, sb1, sb2, s0, m1, m2, m0, v2, v0);
+        if (i + 1 >= n_iter) break;
+        step(i + 1, d2, d0, d1, q2, q1, sb2, s0, sb1, m2, m0, m1, v0, v1);
+        if (i + 2 >= n_iter) break;
+        step(i + 2, d0, d1, d2, q0, q2, s0, sb1, sb2, m0, m1, m2, v1, v2);
+    }
+    flush();
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0 && vmax > -INFINITY) atomicMax(&roi_max[roi_id], f2ord(vmax));
 }
 
 struct SelArgs {
@@ -927,10 +1092,30 @@ static int corner_scratch_setup(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, c
     return KTLVO_OK;
 }
 
+// minw, minh: the smallest ROI of the call; ROIs of at least 8 x 8 pixels that do not go through corner_select's LDS
+// (whole frames) take the register kernel, corner_candidates_wave, unless the context says otherwise.
 static int run_candidates(ktlvo_ctx *ctx, int slot, int n_roi, int maxw, int maxh, int use_harris, double k,
-                          const CornerScratch &s, float *d_resp_out, bool want_candidates, const int *d_roi_slots = nullptr) {
+                          const CornerScratch &s, float *d_resp_out, bool want_candidates, const int *d_roi_slots = nullptr,
+                          bool large = false, int minw = 0, int minh = 0) {
     const double scale = 1.0 / ((double)(1 << 2) * 3 * 255.0); // cornerEigenValsVecs: 2^(ksize-1) * blockSize * 255
     const float s1 = (float)(1.0 * scale), s2 = (float)(2.0 * scale);
+    if (large && ctx->candidates_wave && minw >= 8 && minh >= 8) {
+        CwGrid g;
+        g.strips = (maxw + CW_COLS - 1) / CW_COLS;
+        g.bands = std::max(1, (maxh + 24) / 48);
+        g.band_rows = (maxh + g.bands - 1) / g.bands;
+        const int groups = (g.strips * g.bands * n_roi + 3) / 4;
+        const dim3 grid(8 * ((groups + 7) / 8));
+        unsigned long long *d_cand = want_candidates ? s.d_cand : nullptr;
+        if (use_harris)
+            hipLaunchKernelGGL(corner_candidates_wave<true>, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois, s1, s2, k,
+                               d_resp_out, s.d_max, d_cand, s.d_cnt, g, n_roi, d_roi_slots);
+        else
+            hipLaunchKernelGGL(corner_candidates_wave<false>, grid, dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois, s1, s2, k,
+                               d_resp_out, s.d_max, d_cand, s.d_cnt, g, n_roi, d_roi_slots);
+        KTLVO_HIP(ctx, hipGetLastError());
+        return KTLVO_OK;
+    }
     const int3 tiles = {(maxw + CT - 1) / CT, (maxh + CT - 1) / CT, n_roi};
     const int n_tiles = tiles.x * tiles.y * tiles.z;
     hipLaunchKernelGGL(corner_candidates, dim3(8 * ((n_tiles + 7) / 8)), dim3(256), 0, ctx->stream, ctx->d_slots, slot, s.d_rois,
@@ -1089,7 +1274,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     KTLVO_HIP(ctx, hipMemcpyAsync(d_roi_slots, h_slots, 4 * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
     rc = corner_scratch_setup(ctx, rois.data(), n_frames, s);
     if (rc != KTLVO_OK) return rc;
-    rc = run_candidates(ctx, -1, n_frames, roi.w, roi.h, p->use_harris, p->harris_k, s, nullptr, true, d_roi_slots);
+    rc = run_candidates(ctx, -1, n_frames, roi.w, roi.h, p->use_harris, p->harris_k, s, nullptr, true, d_roi_slots, true, roi.w, roi.h);
     if (rc != KTLVO_OK) return rc;
     const bool dist = p->min_dist >= 1;
     const int cell = dist ? (int)lrint(p->min_dist) : 1;
@@ -1319,7 +1504,8 @@ extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *
     float *d_resp = (float *)((char *)ctx->d_misc + o_resp);
     rc = corner_scratch_setup(ctx, rois, 1, s);
     if (rc != KTLVO_OK) return rc;
-    rc = run_candidates(ctx, slot, 1, maxw, maxh, use_harris, harris_k, s, d_resp, false);
+    rc = run_candidates(ctx, slot, 1, maxw, maxh, use_harris, harris_k, s, d_resp, false, nullptr,
+                        (size_t)maxw * maxh > (size_t)SEL_MAX, maxw, maxh);
     if (rc != KTLVO_OK) return rc;
     KTLVO_HIP(ctx, hipMemcpyAsync(out, d_resp, total * 4, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1368,7 +1554,9 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
         // larger ROIs (whole frames): the candidate counts size the sort, so they come home first
         rc = corner_scratch_setup(ctx, rois, n_roi, s);
         if (rc != KTLVO_OK) return rc;
-        rc = run_candidates(ctx, slot, n_roi, maxw, maxh, p->use_harris, p->harris_k, s, nullptr, true);
+        int minw = maxw, minh = maxh;
+        for (int r = 0; r < n_roi; r++) { minw = std::min(minw, rois[r].w); minh = std::min(minh, rois[r].h); }
+        rc = run_candidates(ctx, slot, n_roi, maxw, maxh, p->use_harris, p->harris_k, s, nullptr, true, nullptr, true, minw, minh);
         if (rc != KTLVO_OK) return rc;
         int *h_cnt = (int *)(hp + out_bytes);
         KTLVO_HIP(ctx, hipMemcpyAsync(h_cnt, s.d_cnt, 4 * (size_t)n_roi, hipMemcpyDeviceToHost, ctx->stream));

@@ -123,6 +123,8 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
         ctx->pyr_per_level = e && e[0] == '1';
         e = getenv("KTLVO_FRAME_PER_STAGE");
         ctx->frame_chain = !(e && e[0] == '1');
+        e = getenv("KTLVO_CANDIDATES_TILES");
+        ctx->candidates_wave = !(e && e[0] == '1');
         e = getenv("KTLVO_FRAMES_GLOBAL_SORT");
         ctx->frames_lds_sort = !(e && e[0] == '1');
     }

@@ -384,6 +384,30 @@ def test_corner_response_bit_exact(make_ctx, oracle):
             assert np.array_equal(g, o), (roi, harris, k)
 
 
+def test_corner_response_large_rois_both_kernels(make_ctx, oracle):
+    """ROIs beyond 4096 pixels take the register kernel (a wave per 58-column strip and band of rows): response maps
+    bit-exact against the oracle for widths around the strip boundaries (58 k - 1, 58 k, 58 k + 1, 58 k + 2), heights
+    that make one, two and several bands, ROIs inside the image (Sobel reads the parent, the box filter reflects at the
+    ROI) and the whole image; the LDS-tile kernel (KTLVO_CANDIDATES_TILES=1) must give the same on the same ROIs."""
+    W, H = 400, 300
+    img = synth.texture_image(W, H, seed=57, periods=(23.0, 9.0, 4.0), noise=True)
+    wave = make_ctx(width=W, height=H)
+    os.environ["KTLVO_CANDIDATES_TILES"] = "1"
+    try:
+        tiles = make_ctx(width=W, height=H)
+    finally:
+        del os.environ["KTLVO_CANDIDATES_TILES"]
+    for ctx in (wave, tiles):
+        ctx.upload_image(0, img)
+    rois = [(0, 0, W, H), (3, 5, 115, 40), (7, 0, 116, 73), (1, 2, 117, 97), (40, 30, 118, 200), (0, 10, 57, 290),
+            (283, 1, 117, 299), (11, 13, 59, 71), (100, 100, 174, 48), (5, 250, 390, 50), (0, 0, 8, 513 // 2 + 30)]
+    for roi in rois:
+        for harris, k in [(False, 0.0), (True, 0.04)]:
+            o = oracle.corner_response(img, roi, harris, k)
+            assert np.array_equal(wave.corner_response(0, roi, harris, k), o), ("wave", roi, harris)
+            assert np.array_equal(tiles.corner_response(0, roi, harris, k), o), ("tiles", roi, harris)
+
+
 def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
     g = np.load(os.path.join(GOLD, "corners_260x180.npz"))
     ctx = make_ctx(width=260, height=180)
