@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
         if (!((votes[q] >> lane) & 1ull)) continue;
         const int oy = oy0 + q;
         const int place = block_base + wave_cnt[wave][q] + __popcll(votes[q] & ((1ull << lane) - 1ull));
-        cand[R.off + place] = ((unsigned long long)f2ord(vals[q]) << 32) | (unsigned)((ty0 + oy) * R.w + (tx0 + ox));
+        cand[R.off + place] = ((unsigned long long)f2ord(vals[q]) << 32) | (unsigned)(((ty0 + oy) << 16) | (tx0 + ox));
     }
 }
 
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
         const bool keep = cand_col && vB > 0.f && vB == m;
         const unsigned long long vote = __ballot(keep);
         if (vote) {
-            if (keep) buf[n_buf + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)f2ord(vB) << 32) | (unsigned)(yo * W + x);
+            if (keep) buf[n_buf + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)f2ord(vB) << 32) | (unsigned)((yo << 16) | x);
             n_buf += __popcll(vote);
             if (n_buf > CW_BUF) flush();
         }
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
         const int m = n < limit ? n : limit;
         for (int i = tid; i < m; i += 256) {
             const unsigned idx = (unsigned)keys[i];
-            oxy[2 * i] = (float)(idx % R.w); oxy[2 * i + 1] = (float)(idx / R.w);
+            oxy[2 * i] = (float)(idx & 0xffffu); oxy[2 * i + 1] = (float)(idx >> 16);
             oresp[i] = ord2f((unsigned)(keys[i] >> 32));
         }
         if (tid == 0) a.counts[roi] = m;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
     int ncorners = 0;
     for (int i = 0; i < n; i++) {
         const unsigned idx = (unsigned)keys[i];
-        const int y = idx / R.w, x = idx - y * R.w;
+        const int y = idx >> 16, x = idx & 0xffffu;
         const int xc = x / cell, yc = y / cell;
         bool conflict = false;
         if (tid < 36) {
@@ -791,7 +791,6 @@ struct SelLargeArgs {
     size_t keys_stride, cells_stride, out_stride;
 };
 constexpr int CH = 512;  // candidates per chunk of the greedy pass
-constexpr int HT = 2048; // chunk-local hash of the survivors' cells (load factor <= 1/4)
 // Grid in LDS: a count (4 bytes) and four places of 2 bytes per cell, a corner being kept as its offset inside its
 // cell (x | y << 8, empty 0xFFFF), which a cell of up to 256 pixels allows.
 constexpr size_t SEL_LDS_PER_CELL = 12;
@@ -805,14 +804,22 @@ static bool grid_fits_lds(int cell, int gw, int gh) {
 // it, so a chunk of CH consecutive candidates is handled in parallel: (1) every candidate is tested
 // against the corners accepted from earlier chunks (the cell grid, owned by this single workgroup; the nine
 // cells around a candidate are nine independent loads); (2) the survivors are
-// compacted in rank order, entered into a hash of their cells in LDS, and each finds, in the nine cells
-// around it, the survivors ranked before it that are too close (a bit mask per survivor); (3) rounds in
+// compacted in rank order, and each is tested against the survivors ranked before it (all pairs, spread
+// over the workgroup's threads), which leaves a bit mask of those too close per survivor; (3) rounds in
 // which a survivor with an accepted predecessor in its mask is rejected, and one whose predecessors are
 // all rejected is accepted, until all are decided -- the lowest undecided survivor always decides, and
 // chains are short because a chunk's candidates are scattered over the frame; (4) the accepted ones take
 // their output places in rank order and enter the grid.
 // LG: the grid lives in LDS (dynamic: gw * gh * SEL_LDS_PER_CELL bytes), where a look-up costs a fraction of the L2
 // round trip that bounds a chunk otherwise; frames whose grid does not fit keep it in global memory.
+// Workgroup barrier of the greedy pass.  With the grid in LDS everything the waves tell each other goes through LDS,
+// so the barrier only has to wait for LDS traffic: the next chunk's keys (fetched a chunk ahead) and the corners
+// written out stay in flight across it, where __syncthreads would wait for both at every barrier.
+template <bool LDS_ONLY>
+__device__ __forceinline__ void sync_wg() {
+    if (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+}
 template <bool LG>
 __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     a.keys += blockIdx.x * a.keys_stride; a.n_ptr += blockIdx.x; a.count += blockIdx.x;
@@ -822,12 +829,12 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     int *const g_cnt = (int *)dyn_lds;                                            // LG: gw * gh counts ...
     unsigned short *const g_pts = (unsigned short *)(dyn_lds + 4 * (size_t)a.gw * a.gh); // ... then gw * gh * 4 places
     __shared__ unsigned long long s_key[CH];
-    __shared__ int s_x[CH], s_y[CH];
-    __shared__ __attribute__((aligned(16))) unsigned conf[CH][CH / 32];
-    __shared__ unsigned ht_key[HT]; // cell index + 1, 0 = empty
-    __shared__ unsigned short ht_val[HT];
+    __shared__ __attribute__((aligned(16))) unsigned s_pt[CH]; // survivors in rank order: x | y << 16
+    __shared__ unsigned conf[CH][CH / 32 + 1];    // survivor i's predecessors within reach, a bit each (rows padded by a word: no two rows on the same banks)
+    __shared__ int s_hit[CH];                     // survivor i has such a predecessor
     __shared__ unsigned accm[CH / 32], rejm[CH / 32];
-    __shared__ int wave_off[CH / 64 + 1];
+    __shared__ int wave_cnt[2][CH / 64];          // per-wave counts of a vote, in turn for the two votes of a chunk
+    __shared__ int s_any[CH / 64];
     __shared__ int s_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = *a.n_ptr;
@@ -838,13 +845,23 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         return (double)(dx * dx + dy * dy) < md2;
     };
     auto too_close = [&](int x, int y, unsigned p) { return too_close_xy(x, y, (int)(p & 0xffff), (int)(p >> 16)); };
+    // n / cell for 0 <= n < 65536 without a division: with M = ceil(2^24 / cell), floor(n M / 2^24) = floor(n / cell)
+    // (the excess n (M cell - 2^24) / (cell 2^24) stays below 1 / cell for n < 2^24 / cell, which covers 16 bits for
+    // cells of up to 256 pixels; larger cells, which only the grid in global memory has, divide)
+    const unsigned cell_m = (unsigned)(((1u << 24) + (unsigned)a.cell - 1u) / (unsigned)a.cell);
+    auto cell_of = [&](int n) { return a.cell <= 256 ? (int)(((unsigned long long)(unsigned)n * cell_m) >> 24) : n / a.cell; };
+    // Distances between points at most two cells apart, in the LDS variant at most 512 pixels: dx, dy and
+    // dx^2 + dy^2 are integers that float holds exactly, so OpenCV's (double)(dx * dx + dy * dy) < minDistance^2 is the
+    // integer comparison with the threshold rounded up.
+    const int md2_up = (int)ceil(md2);
+    auto near = [&](int dx, int dy) { return dx * dx + dy * dy < md2_up; };
     if (tid == 0) s_total = 0;
     if (LG) {
         const int cells = a.gw * a.gh;
         for (int q = tid; q < cells; q += CH) g_cnt[q] = 0;
         for (int q = tid; q < 2 * cells; q += CH) ((unsigned *)g_pts)[q] = 0xFFFFFFFFu;
     }
-    __syncthreads();
+    sync_wg<LG>();
     unsigned long long next_key = tid < n ? a.keys[tid] : 0ull; // a chunk's keys are fetched one chunk ahead
     for (int base = 0; base < n; base += CH) {
         const int total0 = s_total;
@@ -855,7 +872,6 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         // workgroup: they run on one CU and share its L1, so workgroup scope orders it (a wider scope would write back
         // and invalidate the XCD's whole L2 twice per chunk, under every other frame of a batch).
         if (!LG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int q = tid; q < HT; q += CH) ht_key[q] = 0u;
         // (1) against the grid
         const int i = base + tid;
         unsigned long long key = 0;
@@ -864,8 +880,8 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         if (i < n) {
             key = my_key;
             const unsigned idx = (unsigned)key;
-            y = idx / a.w; x = idx - y * a.w;
-            xc = x / a.cell; yc = y / a.cell;
+            y = (int)(idx >> 16); x = (int)(idx & 0xffffu);
+            xc = cell_of(x); yc = cell_of(y);
             bool hit = false;
             if (LG) {
                 uint2 c[9];
@@ -876,12 +892,24 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                     c[q] = *(const uint2 *)(g_pts + 4 * (cy * a.gw + cx));
                     ox[q] = cx * a.cell; oy[q] = cy * a.cell;
                 }
+                // a cell's places fill in order, and a second corner in a cell of min_dist pixels is rare: the places
+                // beyond the first are only looked at when some lane of the wave has one
+                bool more = false;
 #pragma unroll
                 for (int q = 0; q < 9; q++) {
-                    const unsigned v[4] = {c[q].x & 0xffffu, c[q].x >> 16, c[q].y & 0xffffu, c[q].y >> 16};
+                    const unsigned v0 = c[q].x & 0xffffu;
+                    hit = hit | ((v0 != 0xffffu) & near(x - ox[q] - (int)(v0 & 0xff), y - oy[q] - (int)(v0 >> 8)));
+                    more = more | ((c[q].x >> 16) != 0xffffu);
+                }
+                if (__ballot(more)) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        hit = hit || (v[k] != 0xffffu && too_close_xy(x, y, ox[q] + (int)(v[k] & 0xff), oy[q] + (int)(v[k] >> 8)));
+                    for (int q = 0; q < 9; q++) {
+                        const unsigned v[3] = {c[q].x >> 16, c[q].y & 0xffffu, c[q].y >> 16};
+                        const int bx = x - ox[q], by = y - oy[q];
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+                            hit = hit | ((v[k] != 0xffffu) & near(bx - (int)(v[k] & 0xff), by - (int)(v[k] >> 8)));
+                    }
                 }
             } else {
                 uint4 c[9];
@@ -896,70 +924,75 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
             }
             surv = !hit;
         }
-        // (2) survivors in rank order
+        // (2) survivors in rank order.  Every wave adds up the counts of the waves before it itself: one barrier, no
+        // serial pass by one thread.
         const unsigned long long vote = __ballot(surv);
-        if (lane == 0) wave_off[wave] = __popcll(vote);
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < CH / 64; w++) { const int c = wave_off[w]; wave_off[w] = t; t += c; }
-            wave_off[CH / 64] = t;
-        }
-        __syncthreads();
-        const int S = wave_off[CH / 64];
+        if (lane == 0) wave_cnt[0][wave] = __popcll(vote);
+        sync_wg<LG>();
+        int S = 0, before = 0;
+#pragma unroll
+        for (int w = 0; w < CH / 64; w++) { const int c = wave_cnt[0][w]; S += c; before += w < wave ? c : 0; }
         if (surv) {
-            const int p = wave_off[wave] + __popcll(vote & ((1ull << lane) - 1ull));
-            s_key[p] = key; s_x[p] = x; s_y[p] = y;
-            // several survivors of one cell take several places: the probe for a cell walks to the first empty place
-            const unsigned ck = (unsigned)(yc * a.gw + xc) + 1u;
-            unsigned hsh = (ck * 2654435761u) >> 21; // 11 bits
-            while (atomicCAS(&ht_key[hsh], 0u, ck) != 0u) hsh = (hsh + 1) & (HT - 1);
-            ht_val[hsh] = (unsigned short)p;
+            const int p = before + __popcll(vote & ((1ull << lane) - 1ull));
+            s_key[p] = key; s_pt[p] = (unsigned)x | ((unsigned)y << 16);
         }
-        __syncthreads();
-        // survivor `tid` against the survivors ranked before it
-        int state = 3; // 0 undecided, 1 accepted, 2 rejected, 3 not a survivor
-        if (tid < S) {
-            const int mx = s_x[tid], my = s_y[tid];
-            const int mxc = mx / a.cell, myc = my / a.cell;
-            for (int wq = 0; wq < CH / 128; wq++) ((uint4 *)conf[tid])[wq] = uint4{0u, 0u, 0u, 0u};
-            bool any = false;
-            // the nine cells' first probes go out together: most cells hold no survivor of this chunk, and a probe
-            // chain per cell, one after the other, is nine LDS round trips where this is one
-            unsigned ck9[9], h9[9], k9[9];
+        for (int q = tid; q < S * (CH / 32 + 1); q += CH) (&conf[0][0])[q] = 0u;
+        if (tid < S) s_hit[tid] = 0;
+        sync_wg<LG>();
+        // Survivor i against the survivors ranked before it: all pairs.  A chunk's survivors are few (a few dozen once
+        // the strongest corners are placed), and a pair costs a quarter of an LDS read that a whole wave shares and a
+        // handful of instructions, none waiting for another -- a cell hash would find the few neighbours with far fewer
+        // tests, but through chains of dependent LDS reads that took half of a chunk's time.  The threads form CH / S
+        // groups, and group g takes the g-th block of predecessors, four to a read.
+        if (S > 0) {
+            const int ng = max(1, CH / S), g = tid / S, i = tid - g * S;
+            const int blk = (((S + ng - 1) / ng) + 3) & ~3; // predecessors per group, a multiple of four
+            if (g < ng) {
+                const unsigned pi = s_pt[i];
+                const int xi = (int)(pi & 0xffffu), yi = (int)(pi >> 16);
+                const int j_end = min(i, (g + 1) * blk);
+                for (int j0 = g * blk; j0 < j_end; j0 += 4) {
+                    const uint4 q4 = *(const uint4 *)&s_pt[j0]; // entries beyond the survivors are stale and not looked at
+                    const unsigned pj4[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-            for (int c9 = 0; c9 < 9; c9++) {
-                const int cx = mxc + c9 % 3 - 1, cy = myc + c9 / 3 - 1;
-                const bool in = cx >= 0 && cy >= 0 && cx < a.gw && cy < a.gh;
-                ck9[c9] = in ? (unsigned)(cy * a.gw + cx) + 1u : 0u;
-                h9[c9] = (ck9[c9] * 2654435761u) >> 21;
-                k9[c9] = in ? ht_key[h9[c9]] : 0u;
-            }
-#pragma unroll
-            for (int c9 = 0; c9 < 9; c9++) {
-                const unsigned ck = ck9[c9];
-                unsigned kk = k9[c9];
-                for (unsigned hsh = h9[c9]; kk != 0u; hsh = (hsh + 1) & (HT - 1), kk = ht_key[hsh]) {
-                    if (kk != ck) continue;
-                    const int q = ht_val[hsh];
-                    if (q >= tid) continue;
-                    const float dx = (float)(mx - s_x[q]), dy = (float)(my - s_y[q]);
-                    if (fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2) {
-                        conf[tid][q >> 5] |= 1u << (q & 31);
-                        any = true;
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u;
+                        const int dxi = xi - (int)(pj4[u] & 0xffffu), dyi = yi - (int)(pj4[u] >> 16);
+                        bool close;
+                        if (LG) {
+                            close = near(dxi, dyi);
+                        } else {
+                            const float dx = (float)dxi, dy = (float)dyi;
+                            close = fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2;
+                        }
+                        if (close && j < i) {
+                            atomicOr(&conf[i][j >> 5], 1u << (j & 31));
+                            s_hit[i] = 1;
+                        }
                     }
                 }
             }
-            state = any ? 0 : 1;
         }
+        sync_wg<LG>();
+        int state = 3; // 0 undecided, 1 accepted, 2 rejected, 3 not a survivor
+        if (tid < S) state = s_hit[tid] ? 0 : 1;
         // (3) rounds (none when no survivor of the chunk has a predecessor within reach, the usual case)
-        while (__syncthreads_or(state == 0)) {
+        for (;;) {
+            // any survivor still undecided?  (a wave's vote meets the others' in LDS; the barrier further down, which
+            // every wave passes before it votes again, keeps a vote from being overwritten before it has been read)
+            const unsigned long long vu = __ballot(state == 0);
+            if (lane == 0) s_any[wave] = vu != 0ull;
+            sync_wg<LG>();
+            int undecided = 0;
+#pragma unroll
+            for (int w = 0; w < CH / 64; w++) undecided |= s_any[w];
+            if (!undecided) break;
             const unsigned long long va = __ballot(state == 1), vr = __ballot(state == 2);
             if (lane == 0) {
                 accm[2 * wave] = (unsigned)va; accm[2 * wave + 1] = (unsigned)(va >> 32);
                 rejm[2 * wave] = (unsigned)vr; rejm[2 * wave + 1] = (unsigned)(vr >> 32);
             }
-            __syncthreads();
+            sync_wg<LG>();
             if (state == 0) {
                 bool hit = false, pending = false;
                 for (int wq = 0; wq <= (tid >> 5); wq++) {
@@ -973,21 +1006,19 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         }
         // (4) accepted survivors, in rank order
         const unsigned long long va = __ballot(state == 1);
-        if (lane == 0) wave_off[wave] = __popcll(va);
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < CH / 64; w++) { const int c = wave_off[w]; wave_off[w] = t; t += c; }
-            s_total = min(total0 + t, a.limit);
-        }
-        __syncthreads();
+        if (lane == 0) wave_cnt[1][wave] = __popcll(va);
+        sync_wg<LG>();
+        int n_acc = 0, acc_before = 0;
+#pragma unroll
+        for (int w = 0; w < CH / 64; w++) { const int c = wave_cnt[1][w]; n_acc += c; acc_before += w < wave ? c : 0; }
+        if (tid == 0) s_total = min(total0 + n_acc, a.limit); // read at the next chunk's start, beyond the barrier below
         if (state == 1) {
-            const int pos = total0 + wave_off[wave] + __popcll(va & ((1ull << lane) - 1ull));
+            const int pos = total0 + acc_before + __popcll(va & ((1ull << lane) - 1ull));
             if (pos < a.limit) {
-                const int mx = s_x[tid], my = s_y[tid];
+                const int mx = (int)(s_pt[tid] & 0xffffu), my = (int)(s_pt[tid] >> 16);
                 a.xy[2 * pos] = (float)mx; a.xy[2 * pos + 1] = (float)my;
                 a.resp[pos] = ord2f((unsigned)(s_key[tid] >> 32));
-                const int cxi = mx / a.cell, cyi = my / a.cell;
+                const int cxi = cell_of(mx), cyi = cell_of(my);
                 const int ci = cyi * a.gw + cxi;
                 if (LG) {
                     const int slot = atomicAdd(&g_cnt[ci], 1);
@@ -1001,7 +1032,7 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
             }
         }
         if (!LG) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
+        sync_wg<LG>();
     }
     if (tid == 0) *a.count = s_total;
 }
@@ -1015,7 +1046,7 @@ __global__ void corner_take_first(const unsigned long long *keys, const int *n_p
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const unsigned idx = (unsigned)keys[i];
-        xy[2 * i] = (float)(idx % w); xy[2 * i + 1] = (float)(idx / w);
+        xy[2 * i] = (float)(idx & 0xffffu); xy[2 * i + 1] = (float)(idx >> 16);
         resp[i] = ord2f((unsigned)(keys[i] >> 32));
     }
     if (i == 0) *count = n;
