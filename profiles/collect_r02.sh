@@ -19,7 +19,7 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_ANY
 pass grbm GRBM_GUI_ACTIVE
-for mode in frame grid; do
+for mode in frame grid batch; do
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
     n=$(echo $c | cut -d' ' -f1)
     timeout -s KILL 100 rocprofv3 --pmc $c --output-format csv -d $O/det_${mode}_$n -- python3 $R/tools/detect_once.py $mode > $O/det_${mode}_$n.log 2>&1
@@ -27,8 +27,10 @@ for mode in frame grid; do
 done
 timeout -k 10 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/det_trace_frame -- python3 $R/tools/detect_once.py frame > $O/det_trace_frame.log 2>&1
 timeout -k 10 100 rocprofv3 --kernel-trace --stats --output-format csv -d $O/det_trace_grid -- python3 $R/tools/detect_once.py grid > $O/det_trace_grid.log 2>&1
+timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/det_trace_batch -- python3 $R/tools/detect_once.py batch > $O/det_trace_batch.log 2>&1
 cd $R
 python3 profiles/summarize_pmc.py $O/pmc_summary.json $(find $O/pmc_* -name "*counter_collection.csv") > $O/summary.log
 python3 profiles/summarize_pmc.py $O/det_frame_summary.json $(find $O/det_frame_* -name "*counter_collection.csv") > $O/det_frame.log
 python3 profiles/summarize_pmc.py $O/det_grid_summary.json $(find $O/det_grid_* -name "*counter_collection.csv") > $O/det_grid.log
+python3 profiles/summarize_pmc.py $O/det_batch_summary.json $(find $O/det_batch_* -name "*counter_collection.csv") > $O/det_batch.log
 echo collected
