@@ -791,10 +791,12 @@ struct SelLargeArgs {
     size_t keys_stride, cells_stride, out_stride;
 };
 constexpr int CH = 512;  // candidates per chunk of the greedy pass
+constexpr int HT = 2048; // chunk-local hash of the survivors' cells (load factor <= 1/4)
+constexpr int PAIRS_MAX = 192; // survivors of a chunk up to which all pairs are tested; beyond, the cell hash finds the neighbours
 // Grid in LDS: a count (4 bytes) and four places of 2 bytes per cell, a corner being kept as its offset inside its
 // cell (x | y << 8, empty 0xFFFF), which a cell of up to 256 pixels allows.
 constexpr size_t SEL_LDS_PER_CELL = 12;
-constexpr size_t SEL_LDS_GRID_MAX = (size_t)104 << 10; // what the kernel's static arrays leave of a compute unit's 160 KiB
+constexpr size_t SEL_LDS_GRID_MAX = (size_t)100 << 10; // what the kernel's static arrays leave of a compute unit's 160 KiB
 static bool grid_fits_lds(int cell, int gw, int gh) {
     return cell <= 256 && (size_t)gw * gh * SEL_LDS_PER_CELL <= SEL_LDS_GRID_MAX;
 }
@@ -832,6 +834,8 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned s_pt[CH]; // survivors in rank order: x | y << 16
     __shared__ unsigned conf[CH][CH / 32 + 1];    // survivor i's predecessors within reach, a bit each (rows padded by a word: no two rows on the same banks)
     __shared__ int s_hit[CH];                     // survivor i has such a predecessor
+    __shared__ unsigned ht_key[HT];               // many survivors: hash of their cells (cell index + 1, 0 = empty) ...
+    __shared__ unsigned short ht_val[HT];         // ... and the survivor in that place
     __shared__ unsigned accm[CH / 32], rejm[CH / 32];
     __shared__ int wave_cnt[2][CH / 64];          // per-wave counts of a vote, in turn for the two votes of a chunk
     __shared__ int s_any[CH / 64];
@@ -938,13 +942,61 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
         }
         for (int q = tid; q < S * (CH / 32 + 1); q += CH) (&conf[0][0])[q] = 0u;
         if (tid < S) s_hit[tid] = 0;
+        const bool hashed = S > PAIRS_MAX;
+        if (hashed) {
+            for (int q = tid; q < HT; q += CH) ht_key[q] = 0u;
+            sync_wg<LG>();
+            if (surv) { // several survivors of one cell take several places: the probe for a cell walks to the first empty place
+                const int p = before + __popcll(vote & ((1ull << lane) - 1ull));
+                const unsigned ck = (unsigned)(yc * a.gw + xc) + 1u;
+                unsigned hsh = (ck * 2654435761u) >> 21; // 11 bits
+                while (atomicCAS(&ht_key[hsh], 0u, ck) != 0u) hsh = (hsh + 1) & (HT - 1);
+                ht_val[hsh] = (unsigned short)p;
+            }
+        }
         sync_wg<LG>();
         // Survivor i against the survivors ranked before it: all pairs.  A chunk's survivors are few (a few dozen once
         // the strongest corners are placed), and a pair costs a quarter of an LDS read that a whole wave shares and a
         // handful of instructions, none waiting for another -- a cell hash would find the few neighbours with far fewer
         // tests, but through chains of dependent LDS reads that took half of a chunk's time.  The threads form CH / S
         // groups, and group g takes the g-th block of predecessors, four to a read.
-        if (S > 0) {
+        // A chunk with many survivors (the first chunks of a frame, every chunk when the minimum distance is small) would
+        // pay for S^2 pairs; there every survivor looks its neighbours up in a hash of the survivors' cells instead,
+        // the nine cells' first probes going out together.
+        auto close_to = [&](int dxi, int dyi) {
+            if (LG) return near(dxi, dyi);
+            const float dx = (float)dxi, dy = (float)dyi;
+            return fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2;
+        };
+        if (hashed) {
+            if (tid < S) {
+                const int mx = (int)(s_pt[tid] & 0xffffu), my = (int)(s_pt[tid] >> 16);
+                const int mxc = cell_of(mx), myc = cell_of(my);
+                unsigned ck9[9], h9[9], k9[9];
+#pragma unroll
+                for (int c9 = 0; c9 < 9; c9++) {
+                    const int cx = mxc + c9 % 3 - 1, cy = myc + c9 / 3 - 1;
+                    const bool in = cx >= 0 && cy >= 0 && cx < a.gw && cy < a.gh;
+                    ck9[c9] = in ? (unsigned)(cy * a.gw + cx) + 1u : 0u;
+                    h9[c9] = (ck9[c9] * 2654435761u) >> 21;
+                    k9[c9] = in ? ht_key[h9[c9]] : 0u;
+                }
+#pragma unroll
+                for (int c9 = 0; c9 < 9; c9++) {
+                    const unsigned ck = ck9[c9];
+                    unsigned kk = k9[c9];
+                    for (unsigned hsh = h9[c9]; kk != 0u; hsh = (hsh + 1) & (HT - 1), kk = ht_key[hsh]) {
+                        if (kk != ck) continue;
+                        const int q = ht_val[hsh];
+                        if (q >= tid) continue;
+                        if (close_to(mx - (int)(s_pt[q] & 0xffffu), my - (int)(s_pt[q] >> 16))) {
+                            conf[tid][q >> 5] |= 1u << (q & 31);
+                            s_hit[tid] = 1;
+                        }
+                    }
+                }
+            }
+        } else if (S > 0) {
             const int ng = max(1, CH / S), g = tid / S, i = tid - g * S;
             const int blk = (((S + ng - 1) / ng) + 3) & ~3; // predecessors per group, a multiple of four
             if (g < ng) {
@@ -958,14 +1010,7 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
                     for (int u = 0; u < 4; u++) {
                         const int j = j0 + u;
                         const int dxi = xi - (int)(pj4[u] & 0xffffu), dyi = yi - (int)(pj4[u] >> 16);
-                        bool close;
-                        if (LG) {
-                            close = near(dxi, dyi);
-                        } else {
-                            const float dx = (float)dxi, dy = (float)dyi;
-                            close = fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2;
-                        }
-                        if (close && j < i) {
+                        if (close_to(dxi, dyi) && j < i) {
                             atomicOr(&conf[i][j >> 5], 1u << (j & 31));
                             s_hit[i] = 1;
                         }
