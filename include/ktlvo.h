@@ -159,13 +159,15 @@ int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi
 /* cv::goodFeaturesToTrack on the same region of n_frames slots in one call (roi NULL = the whole frame): what
  * featureTracking.cpp:102-103, 421-422 does per image, for a batch of images, as the frame-pair stream and
  * batch workloads need it (2000 to 16384 corners on whole frames).  Every kernel of the whole-frame path takes the
- * frame from its grid, so the batch costs the launches of ONE detection; per frame the result is
- * ktlvo_detect_gftt's for that slot and region.  Outputs [n_frames][cap][2], [n_frames][cap], [n_frames]. */
+ * frame from its grid, so the batch costs three launches (candidates, a sort and a greedy pass with a workgroup per
+ * frame each); per frame the result is ktlvo_detect_gftt's for that slot and region.
+ * Outputs [n_frames][cap][2], [n_frames][cap], [n_frames]. */
 int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi,
                              const ktlvo_gftt_params *params, float *xy, float *response, int *counts, int cap);
-/* The same with DEVICE output arrays, valid once the context's stream has been waited for: corners go straight
- * into ktlvo_pyrlk_batch_dev without a trip through host memory.  The call itself waits once, for the
- * candidate counts that size its sort. */
+/* The same with DEVICE output arrays: corners go straight into ktlvo_pyrlk_batch_dev without a trip through
+ * host memory.  The whole detection is queued in one go and the call waits for it once, at its end (it has to
+ * learn whether some frame had more keys than the per-frame sort holds and must go through the global sort
+ * instead), so the arrays are complete when it returns. */
 int ktlvo_detect_gftt_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi,
                                  const ktlvo_gftt_params *params, float *d_xy, float *d_response, int *d_counts, int cap);
 /* The same detection for callers that must not allocate (code under HIP graph capture, tight serving
