@@ -127,12 +127,7 @@ __device__ __forceinline__ void pyr_store_row(gbyte row, int x, int w, uint32_t 
 // 2 * PD_ROWS + 3 source rows (one 16-byte load each), keeps their horizontal sums in registers as
 // packed uint16 pairs and combines five of them per output row, so nothing goes through LDS.  Each
 // output row is also written to the rows of the top / bottom frame it is mirrored to.
-__global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotList list, int src_level) {
-    const SlotDesc &S = slots[list.s[blockIdx.z]];
-    const LevelDesc src = S.lv[src_level];
-    const LevelDesc dst = S.lv[src_level + 1];
-    const int ox = blockIdx.x * PD_TW + (threadIdx.x & 63) * 4;
-    const int oy0 = blockIdx.y * PD_TH + (threadIdx.x >> 6) * PD_ROWS;
+__device__ __forceinline__ void pyr_down_block(const LevelDesc &src, const LevelDesc &dst, int ox, int oy0) {
     if (ox >= dst.w || oy0 >= dst.h) return;
 
     constexpr int NS = 2 * PD_ROWS + 3;
@@ -159,6 +154,32 @@ __global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotLi
         if (oy >= 1 && oy <= PAD) pyr_store_row(org - (ptrdiff_t)oy * dst.pitch, ox, dst.w, v);
         const int my = 2 * (dst.h - 1) - oy;
         if (oy <= dst.h - 2 && my < dst.h + PAD) pyr_store_row(org + (ptrdiff_t)my * dst.pitch, ox, dst.w, v);
+    }
+}
+__global__ __launch_bounds__(256) void pyr_down_u8(const SlotDesc *slots, SlotList list, int src_level) {
+    const SlotDesc &S = slots[list.s[blockIdx.z]];
+    pyr_down_block(S.lv[src_level], S.lv[src_level + 1], blockIdx.x * PD_TW + (threadIdx.x & 63) * 4,
+                   blockIdx.y * PD_TH + (threadIdx.x >> 6) * PD_ROWS);
+}
+
+// The last two levels of a large batch from ONE launch: a workgroup per image forms level first + 1 from level
+// `first` with pyr_down_u8's own blocks (a 4 x 4 block of outputs per thread, as many rounds as the level needs),
+// waits for its waves, and forms level first + 2 from what it has just written.  At these sizes (a few thousand
+// pixels per image) a launch per level is all latency: descriptor loads, one round of row loads, the stores and the
+// launch itself, some 11 us each for a microsecond of arithmetic.  The second level reads what other waves of the
+// same workgroup stored: they share the compute unit's L1, which held none of these lines before, and the barrier
+// waits for the stores, so workgroup scope orders it.
+constexpr int PT2_THREADS = 512;
+__global__ __launch_bounds__(PT2_THREADS) void pyr_down_tail2(const SlotDesc *slots, SlotList list, int first) {
+    const SlotDesc &S = slots[list.s[blockIdx.x]];
+    for (int l = first; l < first + 2; l++) {
+        const LevelDesc src = S.lv[l], dst = S.lv[l + 1];
+        const int bw = (dst.w + 3) / 4, bh = (dst.h + PD_ROWS - 1) / PD_ROWS;
+        for (int b = threadIdx.x; b < bw * bh; b += PT2_THREADS) {
+            const int by = b / bw, bx = b - by * bw;
+            pyr_down_block(src, dst, bx * 4, by * PD_ROWS);
+        }
+        __syncthreads();
     }
 }
 
@@ -534,7 +555,9 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
             // faster (the fused kernel recomputes halos through LDS, several times over with its small tiles).
             // (KTLVO_PYR_PER_LEVEL=1 in the environment at context creation keeps a launch per level: A/B and tests)
             const bool tail = top == 4 && list.n <= 8 && !ctx->pyr_per_level;
-            for (int l = 0; l < (tail ? 1 : top); l++) {
+            // a large batch: a launch per level down to level 2, then levels 3 and 4 from one launch, a workgroup per image
+            const bool tail2 = top == 4 && !tail && !ctx->pyr_per_level;
+            for (int l = 0; l < (tail ? 1 : tail2 ? 2 : top); l++) {
                 dim3 grid((ctx->lw[l + 1] + PD_TW - 1) / PD_TW, (ctx->lh[l + 1] + PD_TH - 1) / PD_TH, list.n);
                 hipLaunchKernelGGL(pyr_down_u8, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, l);
             }
@@ -542,6 +565,7 @@ extern "C" int ktlvo_build_pyramids(ktlvo_ctx *ctx, const int *slots, int n_slot
                 dim3 grid((ctx->lw[4] + TT - 1) / TT, (ctx->lh[4] + TT - 1) / TT, list.n);
                 hipLaunchKernelGGL(pyr_down_tail3, grid, dim3(256), 0, ctx->stream, ctx->d_slots, list, 1);
             }
+            if (tail2) hipLaunchKernelGGL(pyr_down_tail2, dim3(list.n), dim3(PT2_THREADS), 0, ctx->stream, ctx->d_slots, list, 2);
         }
         KTLVO_HIP(ctx, hipGetLastError());
         {

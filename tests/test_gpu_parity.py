@@ -585,6 +585,44 @@ def test_fused_small_levels_equal_per_level_launches(make_ctx, oracle, size):
     assert 0.05 < ra[1].mean() < 1.0
 
 
+@pytest.mark.parametrize("size", [(1241, 376), (705, 401), (640, 360)])
+def test_large_batch_small_levels_equal_per_level_launches(make_ctx, oracle, size):
+    """A batch of more than eight images forms levels 3 and 4 from one launch, a workgroup per image
+    (pyr_down_tail2), the second level from what the workgroup has just stored.  Against a launch per level
+    (KTLVO_PYR_PER_LEVEL=1) and the oracle: identical levels and derivative planes for every image, and identical
+    LK results for points hugging and leaving every edge, which read the levels' reflect-101 frames."""
+    W, H = size
+    n = 12
+    rng = np.random.default_rng(W * 11 + H)
+    imgs = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+    os.environ["KTLVO_PYR_PER_LEVEL"] = "1"
+    try:
+        ref = make_ctx(width=W, height=H, num_slots=n, max_points=4096)
+    finally:
+        del os.environ["KTLVO_PYR_PER_LEVEL"]
+    new = make_ctx(width=W, height=H, num_slots=n, max_points=4096)
+    for ctx in (ref, new):
+        ctx.upload_images(list(range(n)), imgs)
+        ctx.build_pyramids(list(range(n)))
+    for s_ in (0, 5, 11):
+        po = oracle.Pyramid(imgs[s_], 4, 21)
+        assert po.max_level == 4 == new.pyramid_levels(s_)
+        for l in range(5):
+            lv = po.level(l)
+            assert np.array_equal(new.download_level(s_, l), lv), (s_, l)
+            assert np.array_equal(new.download_scharr(s_, l, lv.shape[1], lv.shape[0]), po.deriv(l)), (s_, l)
+    m = 2000
+    edge = rng.integers(0, 4, m)
+    t_ = rng.uniform(0, 1, m)
+    off = rng.uniform(-24, 24, m)
+    x = np.where(edge == 0, off, np.where(edge == 1, W - 1 + off, t_ * W))
+    y = np.where(edge == 2, off, np.where(edge == 3, H - 1 + off, t_ * H))
+    pts = np.stack([x, y], 1).astype(np.float32)
+    for a_, b_ in ((0, 1), (10, 11), (7, 3)):
+        ra, rb = ref.pyrlk(a_, b_, pts), new.pyrlk(a_, b_, pts)
+        assert all(np.array_equal(p, q) for p, q in zip(ra, rb)), (a_, b_)
+
+
 def test_batched_detection_equals_per_frame_detection(make_ctx, klib):
     """ktlvo_detect_gftt_frames: the whole-frame detector over a batch of frames with the launches of one
     detection.  Every frame's corners, order and responses equal ktlvo_detect_gftt's for that frame: frames of
