@@ -258,15 +258,16 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
 // For ROIs of at least 8 x 8 pixels (mirror rows and columns 1 and n - 2 exist and are distinct from the edges).
 constexpr int CW_COLS = 58;   // own columns of a wave
 constexpr int CW_BUF = 448;   // candidate keys a wave holds before it flushes
+// (the lane at the end of the wave that has no such neighbour reads zero: it is a halo lane)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)b, (int)(unsigned)b, CTRL, 0xF, 0xF, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(b >> 32), (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, false);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 // v with lane `to` replaced by lane `from`'s value (both wave-uniform)
