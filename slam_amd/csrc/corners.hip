@@ -1324,6 +1324,65 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     return KTLVO_OK;
 }
 
+// Whether the LDS sort is worth trying on ROIs of this area.  It is tried without knowing the key counts, and a ROI with
+// more keys above its threshold than it holds sends the whole call through the global sort afterwards, so it is only
+// tried where that is unlikely: textured frames have a local maximum per 25 to 30 pixels, of which the threshold keeps
+// two thirds (a 1241 x 376 frame: 12,400 keys; a 1920 x 1080 frame: four times as many).
+static bool lds_sort_likely(size_t area) { return area <= ((size_t)512 << 10); }
+
+// The same for a list of large ROIs without a word from the device in between: every ROI's keys are filtered and sorted
+// in LDS by one workgroup (corner_sort_frames), then its greedy pass runs; the ROIs take turns on one work area, in
+// stream order.  *d_many_out is a device flag that is raised when some ROI had more keys above its threshold than the
+// LDS sort holds; the caller looks at it once everything has run and then takes select_large for the whole list.
+static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const ktlvo_gftt_params *p, const CornerScratch &s,
+                            float *d_xy, float *d_resp, int *d_counts, int cap, int **d_many_out) {
+    const bool dist = p->min_dist >= 1;
+    const int cell = dist ? (int)lrint(p->min_dist) : 1;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t cells_max = 0; // of the ROIs whose grid stays in global memory
+    for (int r = 0; r < n_roi && dist; r++) {
+        const int gw = (rois[r].w + cell - 1) / cell, gh = (rois[r].h + cell - 1) / cell;
+        if (!grid_fits_lds(cell, gw, gh)) cells_max = std::max(cells_max, (size_t)gw * gh);
+    }
+    const size_t o_n = up((size_t)SORT_CAP * 8), o_flag = o_n + 256, o_cc = o_flag + 256, o_cp = o_cc + up(cells_max * 4);
+    int rc = ensure_aux(ctx, o_cp + up(cells_max * 16));
+    if (rc != KTLVO_OK) return rc;
+    rc = allow_big_lds(ctx, corner_sort_frames, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
+    if (rc != KTLVO_OK) return rc;
+    char *b = (char *)ctx->d_aux;
+    unsigned long long *d_keys = (unsigned long long *)b;
+    int *d_n = (int *)(b + o_n), *d_many = (int *)(b + o_flag);
+    *d_many_out = d_many;
+    KTLVO_HIP(ctx, hipMemsetAsync(d_many, 0, 4, ctx->stream));
+    const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
+    for (int r = 0; r < n_roi; r++) {
+        const RoiDev &R = rois[r];
+        hipLaunchKernelGGL(corner_sort_frames, dim3(1), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand + R.off,
+                           s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, (size_t)0, (size_t)0, d_many);
+        KTLVO_HIP(ctx, hipGetLastError());
+        float *xy = d_xy + (size_t)r * cap * 2, *resp = d_resp + (size_t)r * cap;
+        if (!dist) {
+            hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256), dim3(256), 0, ctx->stream, d_keys, d_n, R.w, limit, xy,
+                               resp, d_counts + r, (size_t)0, (size_t)0);
+            KTLVO_HIP(ctx, hipGetLastError());
+            continue;
+        }
+        SelLargeArgs a;
+        a.keys = d_keys; a.n_ptr = d_n; a.w = R.w; a.h = R.h; a.min_dist = p->min_dist; a.cell = cell;
+        a.gw = (R.w + cell - 1) / cell; a.gh = (R.h + cell - 1) / cell;
+        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
+        a.xy = xy; a.resp = resp; a.count = d_counts + r; a.overflow = s.d_overflow;
+        a.keys_stride = a.cells_stride = a.out_stride = 0;
+        if (!select_uses_lds_grid(a)) {
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, (size_t)a.gw * a.gh * 4, ctx->stream));
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)a.gw * a.gh * 16, ctx->stream));
+        }
+        rc = launch_select_large(ctx, a, 1);
+        if (rc != KTLVO_OK) return rc;
+    }
+    return KTLVO_OK;
+}
+
 // ---- a batch of frames ------------------------------------------------------------------------------------
 // goodFeaturesToTrack on the same ROI of n_frames slots with the launches of ONE detection: every kernel of the
 // whole-frame path takes a frame index from its grid.  A single frame leaves the GPU mostly idle (its greedy pass is
@@ -1364,7 +1423,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     a.xy = d_xy; a.resp = d_resp; a.count = d_counts; a.overflow = s.d_overflow;
     a.cells_stride = cells; a.out_stride = (size_t)cap;
 
-    if (ctx->frames_lds_sort) {
+    if (ctx->frames_lds_sort && lds_sort_likely(area)) {
         // Every frame filtered and sorted by one workgroup in LDS, then the greedy pass: nothing is sized on the host, so
         // the whole detection is queued in one go and the host waits once, at the end, to learn whether a frame had more
         // keys than the LDS sort holds; then, and only then, the global path below does the batch again.
@@ -1614,7 +1673,7 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
     const size_t out_bytes = o_counts + 4 * (size_t)n_roi - o_xy;
     rc = ensure_misc(ctx, o_counts + up(4 * (size_t)n_roi));
     if (rc != KTLVO_OK) return rc;
-    rc = ensure_pin(ctx, out_bytes + 4 * (size_t)n_roi + 8);
+    rc = ensure_pin(ctx, out_bytes + 4 * (size_t)n_roi + 16);
     if (rc != KTLVO_OK) return rc;
     CornerScratch s;
     corner_scratch_carve(ctx->d_misc, n_roi, total, s);
@@ -1628,7 +1687,7 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
         rc = corner_detect_small_dev(ctx, slot, rois, n_roi, maxw, maxh, p, s, d_xy, d_oresp, d_counts, cap);
         if (rc != KTLVO_OK) return rc;
     } else {
-        // larger ROIs (whole frames): the candidate counts size the sort, so they come home first
+        // larger ROIs (whole frames)
         rc = corner_scratch_setup(ctx, rois, n_roi, s);
         if (rc != KTLVO_OK) return rc;
         int minw = maxw, minh = maxh;
@@ -1636,6 +1695,29 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
         rc = run_candidates(ctx, slot, n_roi, maxw, maxh, p->use_harris, p->harris_k, s, nullptr, true, nullptr, true, minw, minh);
         if (rc != KTLVO_OK) return rc;
         int *h_cnt = (int *)(hp + out_bytes);
+        bool try_lds = ctx->frames_lds_sort;
+        for (int r = 0; r < n_roi; r++) try_lds = try_lds && lds_sort_likely((size_t)rois[r].w * rois[r].h);
+        if (try_lds) {
+            // every ROI sorted in LDS and selected without a word from the device in between; the results come home
+            // with a flag that says whether some ROI had too many keys for that, in which case the route below does
+            // the list again
+            int *d_many = nullptr;
+            rc = select_large_lds(ctx, rois, n_roi, p, s, d_xy, d_oresp, d_counts, cap, &d_many);
+            if (rc != KTLVO_OK) return rc;
+            int *h_ovf = (int *)(hp + out_bytes + 4 * (size_t)n_roi), *h_many = h_ovf + 1;
+            KTLVO_HIP(ctx, hipMemcpyAsync(hp, d_xy, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+            KTLVO_HIP(ctx, hipMemcpyAsync(h_many, d_many, 4, hipMemcpyDeviceToHost, ctx->stream));
+            KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (!*h_many) {
+                memcpy(xy, hp, (size_t)n_roi * cap * 8);
+                memcpy(response, hp + (o_or - o_xy), (size_t)n_roi * cap * 4);
+                memcpy(counts, hp + (o_counts - o_xy), 4 * (size_t)n_roi);
+                if (*h_ovf) { ctx->last_error = "corner selection: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
+                return KTLVO_OK;
+            }
+        }
+        // the global sort is sized by the candidate counts, so they come home first
         KTLVO_HIP(ctx, hipMemcpyAsync(h_cnt, s.d_cnt, 4 * (size_t)n_roi, hipMemcpyDeviceToHost, ctx->stream));
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int r = 0; r < n_roi; r++) {

@@ -712,6 +712,11 @@ def test_batched_detection_lds_sort_equals_global_sort(make_ctx, klib):
         for s_, (xa, ra) in zip([0, 1, 2, 3, 1], fast.detect_gftt_frames([0, 1, 2, 3, 1], params)):
             (rxy, rresp), = fast.detect_gftt(s_, [(0, 0, W, H)], params)
             assert np.array_equal(xa, rxy) and np.array_equal(ra, rresp), (s_, len(xa), len(rxy))
+        # per-call detection takes the same two routes: several large ROIs in one call, the noise frame (fallback) too
+        rois = [(0, 0, W, H), (100, 20, 700, 300), (0, 0, 333, H)]
+        for s_ in (0, 4):
+            for (xa, ra), (xb, rb) in zip(fast.detect_gftt(s_, rois, params), slow.detect_gftt(s_, rois, params)):
+                assert np.array_equal(xa, xb) and np.array_equal(ra, rb), (s_, len(xa), len(xb))
     got = fast.detect_gftt_frames([0, 3], klib.gftt_params(2000, 0.01, 10.0, 3, 0, 0.0))
     assert len(got[0][0]) == 2000 and len(got[1][0]) == 0
 
