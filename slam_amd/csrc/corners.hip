@@ -660,25 +660,47 @@ __device__ __forceinline__ void sort_store(u64 *sk, int t, int np2, const u64 (&
 #pragma unroll
     for (int r = 0; r < 16; r++) sk[sort_place(sort_index<LO>(t, r))] = k[r];
 }
+// A compare-exchange on two keys as IEEE doubles.  Every key of a kept candidate has its top bit set (the order-
+// preserving map of a positive response) and a finite exponent field (a finite response), and the padding is zero: read
+// as doubles the keys are negative numbers, ordered the other way round than as unsigned integers, and the padding is
+// +0.0, the largest -- "descending as unsigned" is "ascending as double", zeros last either way.  So the larger key is
+// the smaller double, and a compare-exchange is one v_min_f64 and one v_max_f64 instead of a 64-bit compare and four
+// selects (asm: the builtins would first canonicalise their inputs against signalling NaNs, which these never are).
+__device__ __forceinline__ void sort_ce(u64 &first, u64 &second) { // first gets the larger key
+    const double dx = __builtin_bit_cast(double, first), dy = __builtin_bit_cast(double, second);
+    double mn, mx;
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(dx), "v"(dy));
+    first = __builtin_bit_cast(u64, mn);
+    second = __builtin_bit_cast(u64, mx);
+}
 // the compare-exchanges of stage S for the bits BHI ... LO (all inside the window)
 template <int LO, int S, int BHI>
 __device__ __forceinline__ void sort_steps(int t, int np2, u64 (&k)[16]) {
     if (sort_index<LO>(t, 0) >= np2) return;
     // a run of 2^S keys is sorted descending if bit S of its keys' index is clear: inside the window that is a
-    // property of the register number, above it of the thread
-    const bool asc_t = (sort_index<LO>(t, 0) >> S) & 1;
+    // property of the register number, above it of the thread.  A thread whose runs ascend flips its keys' sign bits
+    // for the duration (which reverses their order as doubles) and exchanges like the others.
+    bool flip = false;
+    if constexpr (S > LO + 3) flip = (sort_index<LO>(t, 0) >> S) & 1;
+    const u64 sign = flip ? 0x8000000000000000ull : 0ull;
+    if constexpr (S > LO + 3) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) k[r] ^= sign;
+    }
 #pragma unroll
     for (int b = BHI; b >= LO; --b) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (r & (1 << (b - LO))) continue;
-            bool asc = asc_t;
+            bool asc = false;
             if constexpr (S <= LO + 3) asc = ((r >> (S - LO)) & 1) != 0;
-            u64 &x = k[r], &y = k[r | (1 << (b - LO))];
-            const bool sw = asc ? x > y : x < y;
-            const u64 nx = sw ? y : x, ny = sw ? x : y;
-            x = nx; y = ny;
+            if (asc) sort_ce(k[r | (1 << (b - LO))], k[r]);
+            else sort_ce(k[r], k[r | (1 << (b - LO))]);
         }
+    }
+    if constexpr (S > LO + 3) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) k[r] ^= sign;
     }
 }
 template <int FROM, int TO>
@@ -724,21 +746,25 @@ __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long l
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) s_n = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) { // uniform trip count
-        const int i = base + tid;
-        u64 key = 0;
-        bool keep = false;
-        if (i < n) {
-            key = cand[i];
-            keep = ord2f((unsigned)(key >> 32)) > thr;
+    for (int base = 0; base < n; base += 4096) { // uniform trip count; four loads in flight per thread
+        u64 key4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * 1024 + tid;
+            key4[u] = i < n ? cand[i] : 0ull; // a zero key is below every threshold's keys (responses kept are positive)
         }
-        const u64 vote = __ballot(keep);
-        int woff = 0;
-        if (lane == 0 && vote) woff = atomicAdd(&s_n, __popcll(vote));
-        woff = __builtin_amdgcn_readfirstlane(woff);
-        if (keep) {
-            const int p = woff + __popcll(vote & ((1ull << lane) - 1ull));
-            if (p < SORT_CAP) sk[sort_place(p)] = key;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 key = key4[u];
+            const bool keep = key != 0ull && ord2f((unsigned)(key >> 32)) > thr;
+            const u64 vote = __ballot(keep);
+            int woff = 0;
+            if (lane == 0 && vote) woff = atomicAdd(&s_n, __popcll(vote));
+            woff = __builtin_amdgcn_readfirstlane(woff);
+            if (keep) {
+                const int p = woff + __popcll(vote & ((1ull << lane) - 1ull));
+                if (p < SORT_CAP) sk[sort_place(p)] = key;
+            }
         }
     }
     __syncthreads();
