@@ -310,9 +310,13 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
     // the box filter reflects at the ROI's edges: covariance column -1 is column 1, column W is column W - 2
     const int lane_m1 = 2 - x0, lane_w = W - x0 + 3;            // lanes of columns -1 and W, if this strip holds them
     const bool fix_left = lane_m1 >= 1, fix_right = lane_w <= 62;
-    const bool top = y0 == 0, bottom = y1 == H;
-    const int iy_first = top ? -1 : y0 - 3, iy_last = bottom ? H : y1 + 2;
-    const int n_iter = iy_last - iy_first + 1 + (bottom ? 1 : 0); // the bottom band's last step has no image row
+    // A band needs the covariance rows y0 - 2 ... y1 + 1.  Row -1 is row 1 (only the top band reaches it: bands are at
+    // least 8 rows), row H is row H - 2 -- which the last band reaches, and also the band before it when the last one
+    // is a single row (several ROIs of different heights share one band height).  The step that would form row H has
+    // no image row to read: "image row H + 1" stands for it.
+    const bool top = y0 == 0;
+    const int iy_first = top ? -1 : y0 - 3, iy_last = min(y1 + 2, H + 1);
+    const int n_iter = iy_last - iy_first + 1;
     const int yr_first = top ? 0 : y0 - 1;
 
     float vmax = -INFINITY;
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
     auto step = [&](const int i, float &dA, float &dB, float &dC, float &qA, float &qC, Sums &sA, Sums &sB,
                     Sums &sC, float &mA, float &mB, float &mC, float &vB, float &vC) __attribute__((always_inline)) {
         const int iy = iy_first + i;
-        const bool virt = bottom && i == n_iter - 1;
+        const bool virt = iy == H + 1;
         const int yc = iy - 1;
         if (!virt) {
             const float a = (float)col[(ptrdiff_t)iy * L.pitch];

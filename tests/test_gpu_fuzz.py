@@ -132,6 +132,37 @@ def test_corners_and_gates_random(make_ctx, oracle, klib):
         ctx.close()
 
 
+def test_large_rois_random(make_ctx, oracle, klib):
+    """ROIs beyond 4096 pixels (the register candidates kernel, the LDS or the global sort, the greedy pass with its grid
+    in LDS or in global memory) at random image sizes, ROI placements, corner counts, qualities and minimum distances:
+    points, order and responses identical to the oracle's goodFeaturesToTrack."""
+    rng = np.random.default_rng(int(os.environ.get("KTLVO_FUZZ_SEED", "4711")))
+    for i in range(int(os.environ.get("KTLVO_FUZZ_CASES", "5"))):
+        w, h = int(rng.integers(100, 900)), int(rng.integers(80, 600))
+        img = synth.texture_image(w, h, seed=int(rng.integers(1, 1 << 30)),
+                                  periods=tuple(float(v) for v in rng.choice([5.0, 9.0, 17.0, 31.0, 47.0], 3, replace=False)),
+                                  noise=bool(i % 2))
+        ctx = make_ctx(width=w, height=h, num_slots=1)
+        ctx.upload_image(0, img)
+        rois = [(0, 0, w, h)]
+        for _ in range(2):
+            rw, rh = int(rng.integers(65, w + 1)), int(rng.integers(65, h + 1))
+            rois.append((int(rng.integers(0, w - rw + 1)), int(rng.integers(0, h - rh + 1)), rw, rh))
+        harris = int(rng.integers(0, 2))
+        gp = klib.gftt_params(int(rng.choice([1, 50, 700, 3000, 20000])), float(rng.choice([0.001, 0.01, 0.1])),
+                              float(rng.choice([0.0, 1.0, 2.5, 5.0, 10.0, 17.0, 40.0])), 3, harris,
+                              0.04 if harris and i % 3 == 0 else 0.0)
+        got = ctx.detect_gftt(0, rois, gp)
+        for roi, (xy, resp) in zip(rois, got):
+            oxy, oresp = oracle.good_features(img, roi, gp.max_corners, gp.quality, gp.min_dist, bool(harris), gp.harris_k)
+            oxy, oresp = np.asarray(oxy, np.float32).reshape(-1, 2), np.asarray(oresp, np.float32)
+            assert np.array_equal(xy, oxy), (w, h, roi, gp.max_corners, gp.quality, gp.min_dist, harris, len(xy), len(oxy))
+            assert np.array_equal(resp, oresp), (w, h, roi)
+        (bxy, bresp), = ctx.detect_gftt_frames([0], gp)                      # the batched route on the whole frame
+        assert np.array_equal(bxy, got[0][0]) and np.array_equal(bresp, got[0][1]), (w, h)
+        ctx.close()
+
+
 def test_lk_noise_frame_within_order_sensitivity(make_ctx, oracle):
     """The sweep's worst frame (seed 1111, 164x140 shifted noise): the kernel's distance from the serial
     oracle is no larger than the distance of the oracle from itself under a different order of the float

@@ -408,6 +408,22 @@ def test_corner_response_large_rois_both_kernels(make_ctx, oracle):
             assert np.array_equal(tiles.corner_response(0, roi, harris, k), o), ("tiles", roi, harris)
 
 
+def test_gftt_large_rois_of_different_heights_in_one_call(make_ctx, oracle, klib):
+    """Several large ROIs in one call share one band height (the tallest ROI's): a shorter ROI can then end one row into
+    a band, and the band before it reaches the ROI's bottom edge, where the box filter reflects.  (Found by the
+    random sweep: 548 x 120 with an ROI of 81 rows lost the corners of row 79.)"""
+    w, h = 548, 120
+    img = synth.texture_image(w, h, seed=1234, periods=(17.0, 9.0, 5.0), noise=True)
+    ctx = make_ctx(width=w, height=h)
+    ctx.upload_image(0, img)
+    rois = [(0, 0, w, h), (17, 30, 529, 81), (11, 21, 508, 93), (3, 0, 500, 41), (0, 79, w, 41), (100, 5, 300, 82)]
+    for gp in (klib.gftt_params(700, 0.1, 1.0, 3, 1, 0.0), klib.gftt_params(3000, 0.01, 5.0, 3, 0, 0.0)):
+        for roi, (xy, resp) in zip(rois, ctx.detect_gftt(0, rois, gp)):
+            oxy, oresp = oracle.good_features(img, roi, gp.max_corners, gp.quality, gp.min_dist, bool(gp.use_harris), gp.harris_k)
+            assert np.array_equal(xy, np.asarray(oxy, np.float32).reshape(-1, 2)), roi
+            assert np.array_equal(resp, np.asarray(oresp, np.float32)), roi
+
+
 def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
     g = np.load(os.path.join(GOLD, "corners_260x180.npz"))
     ctx = make_ctx(width=260, height=180)
