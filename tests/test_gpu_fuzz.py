@@ -97,6 +97,28 @@ def test_pyramid_scharr_lk_random_sizes(make_ctx, oracle, klib):
     assert checked > 1500
 
 
+def test_batched_pyramid_builds_random(make_ctx, oracle):
+    """Pyramid + Scharr builds of 1 to 14 images at random sizes in one call: every route of the small levels (a launch
+    per level, levels 2-4 of a small batch from one launch, levels 3-4 of a large batch from one launch, fewer than five
+    levels) against the oracle, every level and derivative plane of every image."""
+    rng = np.random.default_rng(int(os.environ.get("KTLVO_FUZZ_SEED", "31337")))
+    for i in range(int(os.environ.get("KTLVO_FUZZ_CASES", "6"))):
+        w, h = int(rng.integers(24, 900)), int(rng.integers(24, 600))
+        n = int(rng.integers(1, 15))
+        imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        ctx = make_ctx(width=w, height=h, num_slots=n)
+        ctx.upload_images(list(range(n)), imgs)
+        ctx.build_pyramids(list(range(n)))
+        for s_ in sorted(set([0, n - 1, int(rng.integers(0, n))])):
+            po = oracle.Pyramid(imgs[s_], 4, 21)
+            assert ctx.pyramid_levels(s_) == po.max_level, (w, h, n)
+            for l in range(po.max_level + 1):
+                lv = po.level(l)
+                assert np.array_equal(ctx.download_level(s_, l), lv), (w, h, n, s_, l)
+                assert np.array_equal(ctx.download_scharr(s_, l, lv.shape[1], lv.shape[0]), po.deriv(l)), (w, h, n, s_, l)
+        ctx.close()
+
+
 def test_corners_and_gates_random(make_ctx, oracle, klib):
     rng = np.random.default_rng(int(os.environ.get("KTLVO_FUZZ_SEED", "77")))
     for i in range(int(os.environ.get("KTLVO_FUZZ_CASES", "6"))):
