@@ -185,6 +185,41 @@ def test_large_rois_random(make_ctx, oracle, klib):
         ctx.close()
 
 
+def test_batched_detection_random(make_ctx, oracle, klib):
+    """Batches of 2 to 6 frames of one random size (textures, a flat frame, white noise now and then: key counts from
+    none to beyond what the per-frame LDS sort holds) through ktlvo_detect_gftt_frames at random regions and parameters:
+    frame by frame the oracle's goodFeaturesToTrack."""
+    rng = np.random.default_rng(int(os.environ.get("KTLVO_FUZZ_SEED", "8086")))
+    for i in range(int(os.environ.get("KTLVO_FUZZ_CASES", "4"))):
+        w, h = int(rng.integers(100, 1300)), int(rng.integers(80, 500))
+        n = int(rng.integers(2, 7))
+        imgs = []
+        for f in range(n):
+            kind = int(rng.integers(0, 8))
+            if kind == 0:
+                imgs.append(np.full((h, w), int(rng.integers(0, 256)), np.uint8))
+            elif kind == 1:
+                imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+            else:
+                imgs.append(synth.texture_image(w, h, seed=int(rng.integers(1, 1 << 30)), periods=(31.0, 11.0, 5.0), noise=bool(kind % 2)))
+        ctx = make_ctx(width=w, height=h, num_slots=n)
+        ctx.upload_images(list(range(n)), np.stack(imgs))
+        roi = None
+        if i % 3 == 2:
+            rw, rh = int(rng.integers(65, w + 1)), int(rng.integers(65, h + 1))
+            roi = (int(rng.integers(0, w - rw + 1)), int(rng.integers(0, h - rh + 1)), rw, rh)
+        harris = int(rng.integers(0, 2))
+        gp = klib.gftt_params(int(rng.choice([50, 700, 3000, 20000])), float(rng.choice([0.001, 0.01, 0.1])),
+                              float(rng.choice([0.0, 1.0, 3.0, 7.0, 10.0, 25.0])), 3, harris, 0.0)
+        order = [int(v) for v in rng.permutation(n)]
+        for s_, (xy, resp) in zip(order, ctx.detect_gftt_frames(order, gp, roi)):
+            oxy, oresp = oracle.good_features(imgs[s_], roi, gp.max_corners, gp.quality, gp.min_dist, bool(harris), 0.0)
+            oxy, oresp = np.asarray(oxy, np.float32).reshape(-1, 2), np.asarray(oresp, np.float32)
+            assert np.array_equal(xy, oxy), (w, h, n, s_, roi, gp.max_corners, gp.quality, gp.min_dist, harris, len(xy), len(oxy))
+            assert np.array_equal(resp, oresp), (w, h, n, s_)
+        ctx.close()
+
+
 def test_lk_noise_frame_within_order_sensitivity(make_ctx, oracle):
     """The sweep's worst frame (seed 1111, 164x140 shifted noise): the kernel's distance from the serial
     oracle is no larger than the distance of the oracle from itself under a different order of the float
