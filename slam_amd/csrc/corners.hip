@@ -838,7 +838,8 @@ static bool grid_fits_lds(int cell, int gw, int gh) {
 // against the corners accepted from earlier chunks (the cell grid, owned by this single workgroup; the nine
 // cells around a candidate are nine independent loads); (2) the survivors are
 // compacted in rank order, and each is tested against the survivors ranked before it (all pairs, spread
-// over the workgroup's threads), which leaves a bit mask of those too close per survivor; (3) rounds in
+// over the workgroup's threads, or through a hash of the survivors' cells when there are many), which
+// leaves a bit mask of those too close per survivor; (3) rounds in
 // which a survivor with an accepted predecessor in its mask is rejected, and one whose predecessors are
 // all rejected is accepted, until all are decided -- the lowest undecided survivor always decides, and
 // chains are short because a chunk's candidates are scattered over the frame; (4) the accepted ones take
