@@ -1114,6 +1114,216 @@ __global__ __launch_bounds__(CH) void corner_select_large(SelLargeArgs a) {
     if (tid == 0) *a.count = s_total;
 }
 
+// ---- the greedy pass in rounds (frames whose cell grid does not fit LDS) ------------------------------------------
+// corner_select_large walks a frame's candidates in rank order, one workgroup per frame: for a 1920 x 1080 frame with
+// 26,000 candidates that is fifty chunks against a grid in global memory, a millisecond during which a batch of a few
+// dozen frames leaves most of the GPU idle.  The same result comes out of a relaxation that all candidates of all
+// frames take part in at once.  A candidate's fate depends only on the candidates ranked before it that lie within
+// min_dist of it (its predecessors): it is rejected as soon as one of them is accepted, and accepted as soon as all of
+// them are rejected (a candidate without predecessors at once).  Decisions are final and only taken when they are
+// certain, so rounds in any order and with any interleaving reach the sequential pass's result; on textured frames the
+// undecided shrink by a factor of three to five per round and eight to twelve rounds settle everything.  The first
+// `limit` accepted candidates in rank order are goodFeaturesToTrack's corners: cutting the sequential pass short at
+// `limit` corners changes nothing about the decisions taken before.
+// Candidates are binned by cell first (count, scan, fill: lf_count, lf_scan_cells, lf_scan_blocks, lf_fill; an item
+// holds position and rank) so that a candidate looks at the nine cells around it; the output (lf_block_counts,
+// lf_write) is a rank-ordered compaction.
+// All arrays of frame f lie `*_stride` elements after those of frame f - 1; blockIdx.y = frame.
+struct LfArgs {
+    const unsigned long long *keys; // sorted descending, n_ptr[f] of them
+    const int *n_ptr;
+    unsigned char *state;           // 0 undecided, 1 accepted, 2 rejected
+    int *cell_cnt, *cell_fill;      // candidates per cell; places of the cell already handed out
+    int *start;                     // first place of a cell among its scan block's (LF_SCAN cells)
+    int *blk_off;                   // first place of a scan block
+    uint2 *items;                   // candidates in cell order: (x | y << 16, rank)
+    int *blk_cnt;                   // accepted candidates per block of 1024 ranks
+    int *flags;                     // [round * n_frames + f]: the launch left a candidate of the frame undecided
+    int cell, gw, gh, scan_blocks;
+    double min_dist;
+    int limit;
+    float *xy, *resp;
+    int *count;
+    size_t keys_stride, cells_stride, out_stride, blk_stride;
+    int n_frames;
+};
+constexpr int LF_SCAN = 4096;        // cells per workgroup of the scan
+constexpr int LF_SCAN_BLOCKS = 1024; // at most: grids of up to 4M cells
+constexpr int LF_PEND = 12;          // undecided predecessors a candidate keeps track of within a launch
+constexpr int LF_TRIES = 48;         // times it looks at them again before it leaves the rest to the next launch
+__global__ __launch_bounds__(256) void lf_count(LfArgs a) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_ptr[f]) return;
+    a.state[f * a.keys_stride + i] = 0;
+    const unsigned idx = (unsigned)a.keys[f * a.keys_stride + i];
+    const int c = (int)((idx >> 16) / (unsigned)a.cell) * a.gw + (int)((idx & 0xffffu) / (unsigned)a.cell);
+    atomicAdd(&a.cell_cnt[f * a.cells_stride + c], 1);
+}
+// Exclusive sums of 1024 values, one per thread; *total = their sum (the same in every thread).
+__device__ __forceinline__ int wg_scan_1024(int v, int *s_wave, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int t = s_wave[w];
+        before += w < wave ? t : 0;
+        all += t;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+// The cells' first places in two steps: a workgroup per LF_SCAN cells (four per thread) writes the places within its
+// stretch and the stretch's total, then a workgroup per frame turns the totals into the stretches' first places.
+// A cell's first place is the sum of the two; the entry behind the last cell closes the last cell's range.
+__global__ __launch_bounds__(1024) void lf_scan_cells(LfArgs a) {
+    __shared__ int s_wave[16];
+    const int f = blockIdx.y;
+    const size_t c = f * a.cells_stride + (size_t)blockIdx.x * LF_SCAN + threadIdx.x * 4;
+    const bool in = (size_t)blockIdx.x * LF_SCAN + threadIdx.x * 4 < a.cells_stride; // the stride is a multiple of four
+    const int4 v = in ? *(const int4 *)(a.cell_cnt + c) : int4{0, 0, 0, 0};
+    int total;
+    const int e = wg_scan_1024(v.x + v.y + v.z + v.w, s_wave, &total);
+    if (in) *(int4 *)(a.start + c) = int4{e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z};
+    if (threadIdx.x == 0) a.blk_off[f * LF_SCAN_BLOCKS + blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void lf_scan_blocks(LfArgs a) {
+    __shared__ int s_wave[16];
+    int *b = a.blk_off + blockIdx.x * LF_SCAN_BLOCKS;
+    const int v = (int)threadIdx.x < a.scan_blocks ? b[threadIdx.x] : 0;
+    int total;
+    const int e = wg_scan_1024(v, s_wave, &total);
+    if ((int)threadIdx.x < a.scan_blocks) b[threadIdx.x] = e;
+}
+__device__ __forceinline__ int lf_first(const int *start, const int *blk_off, int c) { return start[c] + blk_off[c / LF_SCAN]; }
+__global__ __launch_bounds__(256) void lf_fill(LfArgs a) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_ptr[f]) return;
+    const unsigned idx = (unsigned)a.keys[f * a.keys_stride + i];
+    const int c = (int)((idx >> 16) / (unsigned)a.cell) * a.gw + (int)((idx & 0xffffu) / (unsigned)a.cell);
+    const int k = lf_first(a.start + f * a.cells_stride, a.blk_off + f * LF_SCAN_BLOCKS, c) +
+                  atomicAdd(&a.cell_fill[f * a.cells_stride + c], 1);
+    a.items[f * a.keys_stride + k] = uint2{idx, (unsigned)i};
+}
+// One launch of the relaxation.  A candidate collects its predecessors within reach from the three rows of cells
+// around it (the three cells of a row are one stretch of the item list; the first four items of every stretch are
+// fetched at once, the rest one by one), reads their states and decides if it can; otherwise it keeps the undecided
+// ones in LDS and looks at them again, up to LF_TRIES times.  Ranks run with the thread index and workgroups start in
+// index order, so a candidate's predecessors belong to workgroups that started no later than its own: most chains
+// settle inside one launch, and what is left (a candidate that ran out of tries, or has more undecided predecessors
+// than it can keep) raises the launch's flag for its frame.
+__global__ __launch_bounds__(256) void lf_round(LfArgs a, int round) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = a.n_ptr[f];
+    if (i >= n) return;
+    unsigned char *state = a.state + f * a.keys_stride;
+    if (__hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    __shared__ int s_pend[256][LF_PEND + 1];
+    int *pend = s_pend[threadIdx.x];
+    const int *start = a.start + f * a.cells_stride, *blk_off = a.blk_off + f * LF_SCAN_BLOCKS;
+    const uint2 *items = a.items + f * a.keys_stride;
+    const unsigned idx = (unsigned)a.keys[f * a.keys_stride + i];
+    const int x = (int)(idx & 0xffffu), y = (int)(idx >> 16), xc = x / a.cell, yc = y / a.cell;
+    const int cx0 = max(xc - 1, 0), cx1 = min(xc + 1, a.gw - 1);
+    const float md = (float)a.min_dist;
+    const double md2 = a.min_dist * a.min_dist;
+    int k0[3], k1[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int cy = yc + r - 1;
+        const bool in = cy >= 0 && cy < a.gh;
+        const int row = (in ? cy : yc) * a.gw;
+        k0[r] = lf_first(start, blk_off, row + cx0);
+        k1[r] = in ? lf_first(start, blk_off, row + cx1 + 1) : k0[r];
+    }
+    uint2 head[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) head[r][j] = items[min(k0[r] + j, n - 1)];
+    bool rejected = false, lost = false;
+    int npend = 0;
+    auto look = [&](uint2 it) {
+        const int q = (int)it.y;
+        if (q >= i) return;
+        const float dx = (float)(x - (int)(it.x & 0xffffu)), dy = (float)(y - (int)(it.x >> 16));
+        if (!(fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2)) return;
+        const unsigned char sq = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sq == 1) rejected = true;
+        else if (sq == 0) { if (npend < LF_PEND) pend[npend++] = q; else lost = true; }
+    };
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (k0[r] + j < k1[r]) look(head[r][j]);
+        for (int k = k0[r] + 4; k < k1[r]; k++) look(items[k]);
+    }
+    // A decision is published the moment it is made, inside the loop: lanes of one wave that wait for each other
+    // would otherwise only see it once the whole wave has left the loop.
+    bool done = false;
+    auto settle = [&]() {
+        if (rejected) __hip_atomic_store(&state[i], (unsigned char)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (npend == 0 && !lost) __hip_atomic_store(&state[i], (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done = rejected || (npend == 0 && !lost);
+    };
+    settle();
+    for (int t = 0; t < LF_TRIES && !done; t++) {
+        __builtin_amdgcn_s_sleep(4);
+        int keep = 0;
+        for (int k = 0; k < npend; k++) {
+            const int q = pend[k];
+            const unsigned char sq = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sq == 1) { rejected = true; break; }
+            if (sq == 0) pend[keep++] = q;
+        }
+        npend = keep;
+        settle();
+        if (lost && !rejected && npend == 0) break; // predecessors it could not keep: the next launch
+    }
+    if (!done) a.flags[round * a.n_frames + f] = 1;
+}
+__global__ __launch_bounds__(1024) void lf_block_counts(LfArgs a) {
+    const int f = blockIdx.y, i = blockIdx.x * 1024 + threadIdx.x;
+    const bool acc = i < a.n_ptr[f] && a.state[f * a.keys_stride + i] == 1;
+    const int c = __syncthreads_count(acc);
+    if (threadIdx.x == 0) a.blk_cnt[f * a.blk_stride + blockIdx.x] = c;
+}
+__global__ __launch_bounds__(1024) void lf_write(LfArgs a) {
+    const int f = blockIdx.y, i = blockIdx.x * 1024 + threadIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n_ptr[f], nblk = (n + 1023) / 1024;
+    __shared__ int s_red[16], s_wave[16];
+    // accepted candidates of the blocks before this one
+    int before = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 1024) before += a.blk_cnt[f * a.blk_stride + b];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 0) s_red[wave] = before;
+    const bool acc = i < n && a.state[f * a.keys_stride + i] == 1;
+    const unsigned long long vote = __ballot(acc);
+    if (lane == 0) s_wave[wave] = __popcll(vote);
+    __syncthreads();
+    int base = 0, in_block = 0, own = 0;
+    for (int w = 0; w < 16; w++) { base += s_red[w]; own += w < wave ? s_wave[w] : 0; in_block += s_wave[w]; }
+    if (acc) {
+        const int pos = base + own + __popcll(vote & ((1ull << lane) - 1ull));
+        if (pos < a.limit) {
+            const unsigned long long key = a.keys[f * a.keys_stride + i];
+            float *xy = a.xy + f * a.out_stride * 2;
+            xy[2 * pos] = (float)((unsigned)key & 0xffffu); xy[2 * pos + 1] = (float)((unsigned)key >> 16);
+            a.resp[f * a.out_stride + pos] = ord2f((unsigned)(key >> 32));
+        }
+    }
+    if ((int)blockIdx.x == max(nblk - 1, 0) && tid == 0) a.count[f] = min(base + in_block, a.limit);
+}
+
 // first `limit` keys of a sorted list, no distance test (min_dist < 1)
 __global__ void corner_take_first(const unsigned long long *keys, const int *n_ptr, int w, int limit, float *xy,
                                   float *resp, int *count, size_t keys_stride, size_t out_stride) {
@@ -1306,9 +1516,64 @@ static int launch_select_large(ktlvo_ctx *ctx, const SelLargeArgs &a, int n_rois
     return KTLVO_OK;
 }
 
+// The greedy pass in rounds over n_frames sorted key lists (np2 keys apart, n_sup bounds every list's length): work
+// memory `work` of rounds_work_bytes(), h_flags = n_frames pinned ints.  After every launch of the relaxation the host
+// looks whether any frame still has an undecided candidate; one launch is the rule.  Returns KTLVO_ERR_STATE for the
+// caller to take the sequential pass if 32 launches have not settled a frame.
+constexpr int LF_MAX_ROUNDS = 32;
+// The sequential pass takes a workgroup per frame and as long for 200 frames as for one; the relaxation uses the whole
+// chip and takes as long as its frames add up to.  Measured on 1920 x 1080 and 3840 x 2160 frames the two meet at
+// about 50 frames per call.
+constexpr int LF_FRAMES_MAX = 48;
+static size_t lf_cells_stride(size_t cells) { return (cells + 1 + 3) & ~(size_t)3; }
+static bool rounds_possible(size_t cells) { return (lf_cells_stride(cells) + LF_SCAN - 1) / LF_SCAN <= (size_t)LF_SCAN_BLOCKS; }
+static size_t rounds_work_bytes(size_t np2, size_t cells, int n_frames) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t F = (size_t)n_frames, cs = lf_cells_stride(cells);
+    return up(np2 * F) + up(np2 * 8 * F) + 2 * up(cs * 4 * F) + up(cs * 4 * F) + up((size_t)LF_SCAN_BLOCKS * 4 * F) +
+           up((np2 / 1024 + 1) * 4 * F) + up((size_t)LF_MAX_ROUNDS * F * 4);
+}
+static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *work, int *h_flags) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t F = (size_t)a.n_frames, cs = lf_cells_stride((size_t)a.gw * a.gh);
+    a.keys_stride = np2; a.cells_stride = cs; a.blk_stride = np2 / 1024 + 1;
+    a.scan_blocks = (int)((cs + LF_SCAN - 1) / LF_SCAN);
+    char *w = work;
+    a.state = (unsigned char *)w; w += up(np2 * F);
+    a.items = (uint2 *)w; w += up(np2 * 8 * F);
+    a.cell_cnt = (int *)w; w += up(cs * 4 * F);
+    a.cell_fill = (int *)w; w += up(cs * 4 * F);
+    a.start = (int *)w; w += up(cs * 4 * F);
+    a.blk_off = (int *)w; w += up((size_t)LF_SCAN_BLOCKS * 4 * F);
+    a.blk_cnt = (int *)w; w += up(a.blk_stride * 4 * F);
+    a.flags = (int *)w;
+    KTLVO_HIP(ctx, hipMemsetAsync(a.cell_cnt, 0, 2 * up(cs * 4 * F), ctx->stream)); // counts and handed-out places
+    KTLVO_HIP(ctx, hipMemsetAsync(a.flags, 0, (size_t)LF_MAX_ROUNDS * F * 4, ctx->stream));
+    const dim3 g256((unsigned)((n_sup + 255) / 256), (unsigned)F), g1024((unsigned)((n_sup + 1023) / 1024), (unsigned)F);
+    hipLaunchKernelGGL(lf_count, g256, dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(lf_scan_cells, dim3((unsigned)a.scan_blocks, (unsigned)F), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(lf_scan_blocks, dim3((unsigned)F), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(lf_fill, g256, dim3(256), 0, ctx->stream, a);
+    KTLVO_HIP(ctx, hipGetLastError());
+    bool settled = false;
+    for (int r = 0; r < LF_MAX_ROUNDS && !settled; r++) {
+        hipLaunchKernelGGL(lf_round, g256, dim3(256), 0, ctx->stream, a, r);
+        KTLVO_HIP(ctx, hipGetLastError());
+        KTLVO_HIP(ctx, hipMemcpyAsync(h_flags, a.flags + (size_t)r * F, 4 * F, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        settled = true;
+        for (size_t f = 0; f < F; f++) settled = settled && h_flags[f] == 0;
+    }
+    if (!settled) return KTLVO_ERR_STATE;
+    hipLaunchKernelGGL(lf_block_counts, g1024, dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(lf_write, g1024, dim3(1024), 0, ctx->stream, a);
+    KTLVO_HIP(ctx, hipGetLastError());
+    return KTLVO_OK;
+}
+
 // Sort + greedy pass of one large ROI on the device.  n_sup = the ROI's candidate count (already on the host).
 static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, const ktlvo_gftt_params *p,
-                        const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap) {
+                        const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap, int *h_flags) {
     if (n_sup == 0) {
         KTLVO_HIP(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
         return KTLVO_OK;
@@ -1320,17 +1585,18 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     const int gw = dist ? (R.w + cell - 1) / cell : 0, gh = dist ? (R.h + cell - 1) / cell : 0;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_keys = 0, o_n = o_keys + up(np2 * 8), o_cc = o_n + 256, o_cp = o_cc + up((size_t)gw * gh * 4);
-    const size_t total = o_cp + up((size_t)gw * gh * 16);
+    const size_t o_rounds = o_cp + up((size_t)gw * gh * 16);
+    const bool rounds = dist && ctx->greedy_rounds && !grid_fits_lds(cell, gw, gh) && rounds_possible((size_t)gw * gh);
+    const size_t total = o_rounds + (rounds ? rounds_work_bytes(np2, (size_t)gw * gh, 1) : 0);
     int rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    // keys, counter and the cells' counts cleared in one go (the sort runs over all np2 keys; zeros sort last);
-    // empty places of the cells hold a far-away point
+    // keys and counter cleared in one go (the sort runs over all np2 keys; zeros sort last); a grid in global memory
+    // is cleared when the sequential pass is taken (its empty places hold a far-away point)
     const bool global_grid = dist && !grid_fits_lds(cell, gw, gh);
-    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc + (global_grid ? up((size_t)gw * gh * 4) : 0), ctx->stream));
-    if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)gw * gh * 16, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream));
     const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
     hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
                        p->quality, d_keys, d_n, (size_t)0, (size_t)0);
@@ -1343,6 +1609,17 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
         hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256), dim3(256), 0, ctx->stream, d_keys, d_n, R.w, limit, d_xy,
                            d_resp, d_count, (size_t)0, (size_t)0);
     } else {
+        if (rounds) { // a frame whose grid does not fit LDS: the relaxation over all candidates at once
+            LfArgs l;
+            l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
+            l.xy = d_xy; l.resp = d_resp; l.count = d_count; l.out_stride = 0; l.n_frames = 1;
+            rc = run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_flags);
+            if (rc != KTLVO_ERR_STATE) return rc;
+        }
+        if (global_grid) {
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, (size_t)gw * gh * 4, ctx->stream));
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)gw * gh * 16, ctx->stream));
+        }
         SelLargeArgs a;
         a.keys = d_keys; a.n_ptr = d_n; a.w = R.w; a.h = R.h; a.min_dist = p->min_dist; a.cell = cell; a.gw = gw; a.gh = gh;
         a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
@@ -1431,7 +1708,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     const size_t o_slots = up(corner_scratch_bytes(n_frames, area * n_frames));
     int rc = ensure_misc(ctx, o_slots + up(4 * (size_t)n_frames));
     if (rc != KTLVO_OK) return rc;
-    rc = ensure_pin(ctx, 8 * (size_t)n_frames + 16);
+    rc = ensure_pin(ctx, 12 * (size_t)n_frames + 48);
     if (rc != KTLVO_OK) return rc;
     CornerScratch s;
     corner_scratch_carve(ctx->d_misc, n_frames, area * n_frames, s);
@@ -1502,14 +1779,15 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     size_t np2 = 1;
     while (np2 < (size_t)n_sup) np2 <<= 1;
     const size_t o_keys = 0, o_n = o_keys + up(np2 * 8 * n_frames), o_cc = o_n + up(4 * (size_t)n_frames);
-    const size_t o_cp = o_cc + up(cells * 4 * n_frames), total = o_cp + up(cells * 16 * n_frames);
+    const size_t o_cp = o_cc + up(cells * 4 * n_frames), o_rounds = o_cp + up(cells * 16 * n_frames);
+    const bool rounds = global_grid && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_MAX;
+    const size_t total = o_rounds + (rounds ? rounds_work_bytes(np2, cells, n_frames) : 0);
     rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, global_grid ? o_cp : o_cc, ctx->stream)); // keys, counters, the cells' counts
-    if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream)); // keys, counters
     const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
     hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
                        p->quality, d_keys, d_n, area, np2);
@@ -1521,10 +1799,24 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
                            roi.w, limit, d_xy, d_resp, d_counts, np2, (size_t)cap);
         KTLVO_HIP(ctx, hipGetLastError());
     } else {
-        a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = np2;
-        a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
-        rc = launch_select_large(ctx, a, n_frames);
-        if (rc != KTLVO_OK) return rc;
+        rc = KTLVO_ERR_STATE;
+        if (rounds) { // frames whose grid does not fit LDS: the relaxation over all candidates of all frames at once
+            LfArgs l;
+            l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
+            l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
+            rc = run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_many + 1);
+            if (rc != KTLVO_OK && rc != KTLVO_ERR_STATE) return rc;
+        }
+        if (rc == KTLVO_ERR_STATE) { // the sequential pass, a workgroup per frame
+            if (global_grid) {
+                KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, cells * 4 * n_frames, ctx->stream));
+                KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+            }
+            a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = np2;
+            a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
+            rc = launch_select_large(ctx, a, n_frames);
+            if (rc != KTLVO_OK) return rc;
+        }
     }
     // the overflow flag lands in pinned memory behind the counts' mirror; a caller that waits for the stream reads it there
     KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1704,7 +1996,7 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
     const size_t out_bytes = o_counts + 4 * (size_t)n_roi - o_xy;
     rc = ensure_misc(ctx, o_counts + up(4 * (size_t)n_roi));
     if (rc != KTLVO_OK) return rc;
-    rc = ensure_pin(ctx, out_bytes + 4 * (size_t)n_roi + 16);
+    rc = ensure_pin(ctx, out_bytes + 4 * (size_t)n_roi + 48);
     if (rc != KTLVO_OK) return rc;
     CornerScratch s;
     corner_scratch_carve(ctx->d_misc, n_roi, total, s);
@@ -1753,7 +2045,7 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int r = 0; r < n_roi; r++) {
             rc = select_large(ctx, rois[r], r, h_cnt[r], p, s, d_xy + (size_t)r * cap * 2, d_oresp + (size_t)r * cap,
-                              d_counts + r, cap);
+                              d_counts + r, cap, (int *)(hp + out_bytes + 4 * (size_t)n_roi + 8));
             if (rc != KTLVO_OK) return rc;
         }
     }

@@ -220,6 +220,39 @@ def test_batched_detection_random(make_ctx, oracle, klib):
         ctx.close()
 
 
+def test_greedy_relaxation_random(make_ctx, oracle, klib):
+    """Frames whose cell grid does not fit LDS (small minimum distances on mid-sized frames, whole and fractional, also
+    2.5, whose cell is narrower than the distance as in OpenCV): the greedy pass runs as a relaxation over all candidates
+    at once.  One to three frames a call through ktlvo_detect_gftt_frames, the first also through ktlvo_detect_gftt,
+    against the oracle's goodFeaturesToTrack."""
+    rng = np.random.default_rng(int(os.environ.get("KTLVO_FUZZ_SEED", "8087")))
+    for i in range(int(os.environ.get("KTLVO_FUZZ_CASES", "4"))):
+        w, h = int(rng.integers(500, 1100)), int(rng.integers(300, 700))
+        n = int(rng.integers(1, 4))
+        imgs = []
+        for f in range(n):
+            kind = int(rng.integers(0, 8))
+            if kind == 0:
+                imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
+            else:
+                imgs.append(synth.texture_image(w, h, seed=int(rng.integers(1, 1 << 30)), periods=(31.0, 11.0, 5.0), noise=bool(kind % 2)))
+        ctx = make_ctx(width=w, height=h, num_slots=n, max_points=50000)
+        ctx.upload_images(list(range(n)), np.stack(imgs))
+        harris = int(rng.integers(0, 2))
+        gp = klib.gftt_params(int(rng.choice([300, 5000, 50000])), float(rng.choice([0.0005, 0.01, 0.05])),
+                              float(rng.choice([1.0, 1.5, 2.0, 2.5, 2.9, 3.5, 4.2])), 3, harris, 0.0)
+        want = []
+        for f in range(n):
+            oxy, oresp = oracle.good_features(imgs[f], None, gp.max_corners, gp.quality, gp.min_dist, bool(harris), 0.0)
+            want.append((np.asarray(oxy, np.float32).reshape(-1, 2), np.asarray(oresp, np.float32)))
+        for f, (xy, resp) in enumerate(ctx.detect_gftt_frames(list(range(n)), gp)):
+            assert np.array_equal(xy, want[f][0]), (w, h, n, f, gp.max_corners, gp.quality, gp.min_dist, harris, len(xy), len(want[f][0]))
+            assert np.array_equal(resp, want[f][1]), (w, h, n, f)
+        xy, resp = ctx.detect_gftt(0, [(0, 0, w, h)], gp)[0]
+        assert np.array_equal(xy, want[0][0]) and np.array_equal(resp, want[0][1]), (w, h, gp.max_corners, gp.quality, gp.min_dist, harris)
+        ctx.close()
+
+
 def test_lk_noise_frame_within_order_sensitivity(make_ctx, oracle):
     """The sweep's worst frame (seed 1111, 164x140 shifted noise): the kernel's distance from the serial
     oracle is no larger than the distance of the oracle from itself under a different order of the float

@@ -424,6 +424,40 @@ def test_gftt_large_rois_of_different_heights_in_one_call(make_ctx, oracle, klib
             assert np.array_equal(resp, np.asarray(oresp, np.float32)), roi
 
 
+def test_greedy_pass_in_rounds_equals_sequential_pass(make_ctx, oracle, klib):
+    """Frames whose cell grid does not fit LDS take the greedy pass as a relaxation over all candidates at once; a
+    context created with KTLVO_GREEDY_SEQUENTIAL=1 walks them in rank order, a workgroup per frame.  Same corners, order
+    and responses, per call and for a batch, with the corner limit cutting early, late and not at all, at small and
+    fractional minimum distances, and on white noise (long lists, every cell occupied); and against the oracle."""
+    W, H = 960, 540
+    rng = np.random.default_rng(404)
+    imgs = [synth.texture_image(W, H, seed=90 + i, periods=(19.0, 7.0, 4.0), noise=True) for i in range(3)]
+    imgs.append(rng.integers(0, 256, (H, W), dtype=np.uint8))
+    imgs.append(np.full((H, W), 13, np.uint8))
+    n = len(imgs)
+    par = make_ctx(width=W, height=H, num_slots=n, max_points=20000)
+    os.environ["KTLVO_GREEDY_SEQUENTIAL"] = "1"
+    try:
+        seq = make_ctx(width=W, height=H, num_slots=n, max_points=20000)
+    finally:
+        del os.environ["KTLVO_GREEDY_SEQUENTIAL"]
+    for ctx in (par, seq):
+        ctx.upload_images(list(range(n)), np.stack(imgs))
+    for gp in (klib.gftt_params(8000, 0.01, 5.0, 3, 0, 0.0), klib.gftt_params(300, 0.01, 3.0, 3, 0, 0.0),
+               klib.gftt_params(20000, 0.001, 2.5, 3, 0, 0.0), klib.gftt_params(20000, 0.05, 1.0, 3, 1, 0.04),
+               klib.gftt_params(5000, 0.01, 4.0, 3, 1, 0.0)):
+        a = par.detect_gftt_frames(list(range(n)), gp)
+        b = seq.detect_gftt_frames(list(range(n)), gp)
+        for f, ((xa, ra), (xb, rb)) in enumerate(zip(a, b)):
+            assert np.array_equal(xa, xb) and np.array_equal(ra, rb), (f, gp.max_corners, gp.min_dist, len(xa), len(xb))
+        for f in (0, 3):
+            (xa, ra), = par.detect_gftt(f, [(0, 0, W, H)], gp)
+            assert np.array_equal(xa, a[f][0]) and np.array_equal(ra, a[f][1]), (f, gp.min_dist)
+        oxy, oresp = oracle.good_features(imgs[1], None, gp.max_corners, gp.quality, gp.min_dist, bool(gp.use_harris), gp.harris_k)
+        assert np.array_equal(a[1][0], np.asarray(oxy, np.float32).reshape(-1, 2)) and np.array_equal(a[1][1], np.asarray(oresp, np.float32))
+    assert len(a[4][0]) == 0
+
+
 def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
     g = np.load(os.path.join(GOLD, "corners_260x180.npz"))
     ctx = make_ctx(width=260, height=180)
