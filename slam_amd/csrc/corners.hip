@@ -739,41 +739,199 @@ __device__ __forceinline__ void sort_stage(u64 *sk, int t, int np2, u64 (&k)[16]
     }
     sort_steps<0, S, cmin(S - 1, 3)>(t, np2, k);
 }
+// Frames with more keys than one workgroup sorts: the keys above the threshold are split by response into stretches
+// ("buckets") of at most SORT_CAP keys, each sorted by a workgroup of its own behind the stronger ones.  Four launches:
+// corner_sort_hist counts the keys in PLAN_BINS bins of equal width in the responses' ordered integer form, strongest
+// first (a workgroup per PLAN_SLICE candidates: histogram in LDS, then added to the frame's in global memory);
+// corner_sort_plan (a workgroup per frame) cuts the row of bins wherever the running count passes a multiple of PLAN_T
+// -- a bucket then holds fewer than PLAN_T keys plus one bin's, which is why a bin with more than SORT_CAP - PLAN_T
+// keys (thousands of equal responses) sends the call to the global sort, as do more than SORT_MAXB buckets;
+// corner_sort_scatter moves every key into its bucket's stretch of the output (a workgroup per PLAN_SLICE candidates
+// claims a run of places per bucket); corner_sort_frames<true> sorts each stretch where it lies.
+constexpr int PLAN_BINS = 8192, PLAN_T = 7680, SORT_MAXB = 63, PLAN_SLICE = 16384;
+struct SortPlan {
+    unsigned max_ord;
+    int shift, nb, total;
+    int first_bin[SORT_MAXB + 1]; // bucket b holds bins first_bin[b] ... first_bin[b + 1] - 1
+    int off[SORT_MAXB + 1];       // and starts at this place of the sorted list
+    int cursor[SORT_MAXB + 1];    // places of the bucket's stretch already claimed
+};
+__device__ __forceinline__ int wg_scan_1024(int v, int *s_wave, int *total);
+__device__ __forceinline__ int plan_shift(unsigned omax, float thr) {
+    const unsigned othr = f2ord(thr), span = omax > othr ? omax - othr : 0u;
+    int shift = 0;
+    while ((span >> shift) >= (unsigned)PLAN_BINS) shift++;
+    return shift;
+}
+__device__ __forceinline__ unsigned plan_bin(unsigned omax, int shift, u64 key) {
+    return min((omax - (unsigned)(key >> 32)) >> shift, (unsigned)PLAN_BINS - 1);
+}
+__global__ __launch_bounds__(1024) void corner_sort_hist(const unsigned long long *cand, const int *cand_cnt,
+                                                         const unsigned *roi_max, double quality, size_t cand_stride, int *g_hist) {
+    __shared__ int hist[PLAN_BINS];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int n = cand_cnt[f], base0 = blockIdx.x * PLAN_SLICE;
+    if (base0 >= n) return;
+    cand += f * cand_stride;
+    const unsigned omax = roi_max[f];
+    const float thr = roi_threshold(omax, quality);
+    const int shift = plan_shift(omax, thr);
+    for (int i = tid; i < PLAN_BINS; i += 1024) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PLAN_SLICE / 4096; q++) {
+        u64 key4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base0 + q * 4096 + u * 1024 + tid;
+            key4[u] = i < n ? cand[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (key4[u] != 0ull && ord2f((unsigned)(key4[u] >> 32)) > thr) atomicAdd(&hist[plan_bin(omax, shift, key4[u])], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < PLAN_BINS; i += 1024) {
+        const int c = hist[i];
+        if (c) atomicAdd(&g_hist[(size_t)f * PLAN_BINS + i], c);
+    }
+}
+__global__ __launch_bounds__(1024) void corner_sort_plan(const int *g_hist, const unsigned *roi_max, double quality, SortPlan *plans,
+                                                         int *out_cnt, int *too_many) {
+    __shared__ int pre[PLAN_BINS];
+    __shared__ int s_wave[16], s_first[SORT_MAXB + 2], s_maxbin;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const unsigned omax = roi_max[f];
+    if (tid < SORT_MAXB + 2) s_first[tid] = PLAN_BINS;
+    if (tid == 0) s_maxbin = 0;
+    __syncthreads();
+    int c[8], sum = 0, mx = 0;
+    const int4 lo = *(const int4 *)(g_hist + (size_t)f * PLAN_BINS + tid * 8), hi = *(const int4 *)(g_hist + (size_t)f * PLAN_BINS + tid * 8 + 4);
+    c[0] = lo.x; c[1] = lo.y; c[2] = lo.z; c[3] = lo.w; c[4] = hi.x; c[5] = hi.y; c[6] = hi.z; c[7] = hi.w;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sum += c[j]; mx = max(mx, c[j]); }
+    int total;
+    int e = wg_scan_1024(sum, s_wave, &total);
+    if (mx > 0) atomicMax(&s_maxbin, mx);
+    // a bin's bucket is the running count before it over PLAN_T; the first bin of a bucket is the lowest that has it
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        pre[tid * 8 + j] = e;
+        if (c[j] > 0 && e / PLAN_T <= SORT_MAXB) atomicMin(&s_first[e / PLAN_T], tid * 8 + j);
+        e += c[j];
+    }
+    __syncthreads();
+    const int nb = total > 0 ? (total - 1) / PLAN_T + 1 : 0;
+    const bool bad = nb > SORT_MAXB || s_maxbin > SORT_CAP - PLAN_T;
+    if (tid == 0) { // buckets no bin starts in are empty: they begin where the next one does
+        for (int b = SORT_MAXB; b >= 0; --b)
+            if (s_first[b] == PLAN_BINS) s_first[b] = s_first[b + 1];
+    }
+    __syncthreads();
+    SortPlan &P = plans[f];
+    if (tid <= SORT_MAXB) {
+        const int fb = s_first[tid];
+        P.first_bin[tid] = fb;
+        P.off[tid] = fb == PLAN_BINS ? total : pre[fb];
+        P.cursor[tid] = 0;
+    }
+    if (tid == 0) {
+        P.max_ord = omax; P.shift = plan_shift(omax, roi_threshold(omax, quality)); P.nb = bad ? 0 : nb; P.total = total;
+        out_cnt[f] = bad ? 0 : total;
+        if (bad) *too_many = 1;
+    }
+}
+__global__ __launch_bounds__(1024) void corner_sort_scatter(const unsigned long long *cand, const int *cand_cnt,
+                                                            const unsigned *roi_max, double quality, size_t cand_stride,
+                                                            SortPlan *plans, unsigned long long *out, size_t out_stride) {
+    __shared__ int s_first[SORT_MAXB + 1], s_cnt[SORT_MAXB + 1], s_base[SORT_MAXB + 1];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int n = cand_cnt[f], base0 = blockIdx.x * PLAN_SLICE;
+    SortPlan &P = plans[f];
+    if (base0 >= n || P.nb == 0) return;
+    cand += f * cand_stride; out += f * out_stride;
+    const unsigned omax = P.max_ord;
+    const int shift = P.shift;
+    const float thr = roi_threshold(roi_max[f], quality);
+    if (tid <= SORT_MAXB) { s_first[tid] = P.first_bin[tid]; s_cnt[tid] = 0; }
+    __syncthreads();
+    u64 key[PLAN_SLICE / 1024];
+    int where[PLAN_SLICE / 1024]; // bucket << 16 | place among the workgroup's keys of that bucket; -1: not kept
+#pragma unroll
+    for (int q = 0; q < PLAN_SLICE / 1024; q++) {
+        const int i = base0 + q * 1024 + tid;
+        key[q] = i < n ? cand[i] : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < PLAN_SLICE / 1024; q++) {
+        where[q] = -1;
+        if (key[q] != 0ull && ord2f((unsigned)(key[q] >> 32)) > thr) {
+            const int bin = (int)plan_bin(omax, shift, key[q]);
+            int b = 0; // the last bucket whose first bin is not beyond this one
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (b + step <= SORT_MAXB && s_first[b + step] <= bin) b += step;
+            where[q] = (b << 16) | atomicAdd(&s_cnt[b], 1);
+        }
+    }
+    __syncthreads();
+    if (tid <= SORT_MAXB) s_base[tid] = s_cnt[tid] ? P.off[tid] + atomicAdd(&P.cursor[tid], s_cnt[tid]) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PLAN_SLICE / 1024; q++)
+        if (where[q] >= 0) out[s_base[where[q] >> 16] + (where[q] & 0xffff)] = key[q];
+}
+
+// BUCKETS: blockIdx.y = the bucket of frame blockIdx.x the workgroup sorts, after plans[]; the frame's count is the plan's.
+template <bool BUCKETS>
 __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long long *cand, const int *cand_cnt,
                                                            const unsigned *roi_max, double quality, unsigned long long *out,
-                                                           int *out_cnt, size_t cand_stride, size_t out_stride, int *too_many) {
+                                                           int *out_cnt, size_t cand_stride, size_t out_stride, int *too_many,
+                                                           const SortPlan *plans) {
     extern __shared__ u64 sk[]; // SORT_LDS_KEYS keys
     __shared__ int s_n;
     cand += blockIdx.x * cand_stride; out += blockIdx.x * out_stride;
     const int n = cand_cnt[blockIdx.x];
     const float thr = roi_threshold(roi_max[blockIdx.x], quality);
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 4096) { // uniform trip count; four loads in flight per thread
-        u64 key4[4];
+    if constexpr (BUCKETS) { // the stretch is already in out[]: bring it into LDS
+        const SortPlan &P = plans[blockIdx.x];
+        const int b = blockIdx.y;
+        if (b >= P.nb) return;
+        const int lo = P.off[b], cnt = (b == SORT_MAXB ? P.total : P.off[b + 1]) - lo;
+        if (cnt <= 0) return;
+        out += lo;
+        if (cnt <= SORT_CAP)
+            for (int i = tid; i < cnt; i += 1024) sk[sort_place(i)] = out[i];
+        if (tid == 0) s_n = cnt;
+    } else {
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 4096) { // uniform trip count; four loads in flight per thread
+            u64 key4[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = base + u * 1024 + tid;
-            key4[u] = i < n ? cand[i] : 0ull; // a zero key is below every threshold's keys (responses kept are positive)
-        }
+            for (int u = 0; u < 4; u++) {
+                const int i = base + u * 1024 + tid;
+                key4[u] = i < n ? cand[i] : 0ull; // a zero key is below every threshold's keys (responses kept are positive)
+            }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const u64 key = key4[u];
-            const bool keep = key != 0ull && ord2f((unsigned)(key >> 32)) > thr;
-            const u64 vote = __ballot(keep);
-            int woff = 0;
-            if (lane == 0 && vote) woff = atomicAdd(&s_n, __popcll(vote));
-            woff = __builtin_amdgcn_readfirstlane(woff);
-            if (keep) {
-                const int p = woff + __popcll(vote & ((1ull << lane) - 1ull));
-                if (p < SORT_CAP) sk[sort_place(p)] = key;
+            for (int u = 0; u < 4; u++) {
+                const u64 key = key4[u];
+                const bool keep = key != 0ull && ord2f((unsigned)(key >> 32)) > thr;
+                const u64 vote = __ballot(keep);
+                int woff = 0;
+                if (lane == 0 && vote) woff = atomicAdd(&s_n, __popcll(vote));
+                woff = __builtin_amdgcn_readfirstlane(woff);
+                if (keep) {
+                    const int p = woff + __popcll(vote & ((1ull << lane) - 1ull));
+                    if (p < SORT_CAP) sk[sort_place(p)] = key;
+                }
             }
         }
     }
     __syncthreads();
     const int m = s_n;
-    if (m > SORT_CAP) {
+    if (m > SORT_CAP) { // (with buckets: cannot happen after a plan that was not turned down)
         if (tid == 0) { out_cnt[blockIdx.x] = 0; *too_many = 1; }
         return;
     }
@@ -803,7 +961,7 @@ __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long l
 #pragma unroll
     for (int r = 0; r < 16; r++)
         if (16 * tid + r < m) out[16 * tid + r] = k[r];
-    if (tid == 0) out_cnt[blockIdx.x] = m;
+    if (!BUCKETS && tid == 0) out_cnt[blockIdx.x] = m;
 }
 
 struct SelLargeArgs {
@@ -1500,6 +1658,38 @@ static int allow_big_lds(ktlvo_ctx *ctx, K kernel, size_t bytes, bool &done) {
     done = true;
     return KTLVO_OK;
 }
+// Filter and sort of n_lists candidate lists (cand_stride keys apart; counts and maxima one element apart) with more
+// keys than one workgroup sorts, by response ranges (corner_sort_hist, corner_sort_plan, corner_sort_scatter,
+// corner_sort_frames<true>).  n_sup = the largest candidate count, d_work = n_lists plans, a flag and n_lists
+// histograms (bucket_work_bytes), h_flag = one pinned int.  *sorted says whether out[] (lists out_stride keys apart) and out_cnt[]
+// are now what cand_filter and sort_keys would have left at the lists' fronts; if not (a list the plan turned down),
+// the caller takes those two.
+static size_t bucket_plans_bytes(int n_lists) { return (sizeof(SortPlan) * (size_t)n_lists + 255) & ~(size_t)255; }
+static size_t bucket_work_bytes(int n_lists) { return bucket_plans_bytes(n_lists) + 256 + (size_t)n_lists * PLAN_BINS * 4; }
+static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const int *d_cnt, const unsigned *d_max, double quality,
+                       unsigned long long *d_out, int *d_out_cnt, size_t cand_stride, size_t out_stride, int n_lists, int n_sup,
+                       char *d_work, int *h_flag, bool *sorted) {
+    SortPlan *d_plans = (SortPlan *)d_work;
+    int *d_flag = (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_flag + 64;
+    int rc = allow_big_lds(ctx, corner_sort_frames<true>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort_buckets);
+    if (rc != KTLVO_OK) return rc;
+    KTLVO_HIP(ctx, hipMemsetAsync(d_flag, 0, 256 + (size_t)n_lists * PLAN_BINS * 4, ctx->stream)); // flag and histograms
+    const dim3 slices((unsigned)((n_sup + PLAN_SLICE - 1) / PLAN_SLICE), (unsigned)n_lists);
+    hipLaunchKernelGGL(corner_sort_hist, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_hist);
+    hipLaunchKernelGGL(corner_sort_plan, dim3((unsigned)n_lists), dim3(1024), 0, ctx->stream, (const int *)d_hist, d_max, quality,
+                       d_plans, d_out_cnt, d_flag);
+    hipLaunchKernelGGL(corner_sort_scatter, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_plans,
+                       d_out, out_stride);
+    const unsigned nb = (unsigned)std::min(SORT_MAXB, n_sup / PLAN_T + 1);
+    hipLaunchKernelGGL(corner_sort_frames<true>, dim3((unsigned)n_lists, nb), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
+                       d_cand, d_cnt, d_max, quality, d_out, d_out_cnt, cand_stride, out_stride, d_flag, (const SortPlan *)d_plans);
+    KTLVO_HIP(ctx, hipGetLastError());
+    KTLVO_HIP(ctx, hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *sorted = *h_flag == 0;
+    return KTLVO_OK;
+}
+
 // The greedy pass over n_rois sorted key lists, the grid in LDS when it fits (the cells in global memory are then not
 // used and need not be cleared).
 static bool select_uses_lds_grid(const SelLargeArgs &a) { return grid_fits_lds(a.cell, a.gw, a.gh); }
@@ -1587,23 +1777,32 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     const size_t o_keys = 0, o_n = o_keys + up(np2 * 8), o_cc = o_n + 256, o_cp = o_cc + up((size_t)gw * gh * 4);
     const size_t o_rounds = o_cp + up((size_t)gw * gh * 16);
     const bool rounds = dist && ctx->greedy_rounds && !grid_fits_lds(cell, gw, gh) && rounds_possible((size_t)gw * gh);
-    const size_t total = o_rounds + (rounds ? rounds_work_bytes(np2, (size_t)gw * gh, 1) : 0);
+    const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(np2, (size_t)gw * gh, 1) : 0);
+    const size_t total = o_bucket + bucket_work_bytes(1);
     int rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    // keys and counter cleared in one go (the sort runs over all np2 keys; zeros sort last); a grid in global memory
-    // is cleared when the sequential pass is taken (its empty places hold a far-away point)
     const bool global_grid = dist && !grid_fits_lds(cell, gw, gh);
-    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream));
-    const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
-    hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
-                       p->quality, d_keys, d_n, (size_t)0, (size_t)0);
-    KTLVO_HIP(ctx, hipGetLastError());
-    // How many passed is only known on the device; the sort is sized for the candidate count, which bounds it.
-    rc = sort_keys(ctx, d_keys, np2, 1, d_n);
-    if (rc != KTLVO_OK) return rc;
+    bool sorted = false;
+    if (ctx->frames_lds_sort) { // by response ranges in LDS
+        rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi, p->quality, d_keys, d_n, 0, 0, 1, n_sup, b + o_bucket,
+                         h_flags, &sorted);
+        if (rc != KTLVO_OK) return rc;
+    }
+    if (!sorted) {
+        // keys and counter cleared in one go (the sort runs over all np2 keys; zeros sort last); a grid in global memory
+        // is cleared when the sequential pass is taken (its empty places hold a far-away point)
+        KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream));
+        const int fblocks = (int)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
+        hipLaunchKernelGGL(cand_filter, dim3(fblocks), dim3(256), 0, ctx->stream, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi,
+                           p->quality, d_keys, d_n, (size_t)0, (size_t)0);
+        KTLVO_HIP(ctx, hipGetLastError());
+        // How many passed is only known on the device; the sort is sized for the candidate count, which bounds it.
+        rc = sort_keys(ctx, d_keys, np2, 1, d_n);
+        if (rc != KTLVO_OK) return rc;
+    }
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     if (!dist) {
         hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256), dim3(256), 0, ctx->stream, d_keys, d_n, R.w, limit, d_xy,
@@ -1655,7 +1854,7 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
     const size_t o_n = up((size_t)SORT_CAP * 8), o_flag = o_n + 256, o_cc = o_flag + 256, o_cp = o_cc + up(cells_max * 4);
     int rc = ensure_aux(ctx, o_cp + up(cells_max * 16));
     if (rc != KTLVO_OK) return rc;
-    rc = allow_big_lds(ctx, corner_sort_frames, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
+    rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)b;
@@ -1665,8 +1864,8 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     for (int r = 0; r < n_roi; r++) {
         const RoiDev &R = rois[r];
-        hipLaunchKernelGGL(corner_sort_frames, dim3(1), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand + R.off,
-                           s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, (size_t)0, (size_t)0, d_many);
+        hipLaunchKernelGGL(corner_sort_frames<false>, dim3(1), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand + R.off,
+                           s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, (size_t)0, (size_t)0, d_many, (const SortPlan *)nullptr);
         KTLVO_HIP(ctx, hipGetLastError());
         float *xy = d_xy + (size_t)r * cap * 2, *resp = d_resp + (size_t)r * cap;
         if (!dist) {
@@ -1740,15 +1939,15 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         const size_t total = o_cp + (global_grid ? up(cells * 16 * n_frames) : 0);
         rc = ensure_aux(ctx, total);
         if (rc != KTLVO_OK) return rc;
-        rc = allow_big_lds(ctx, corner_sort_frames, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
+        rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
         if (rc != KTLVO_OK) return rc;
         char *b = (char *)ctx->d_aux;
         unsigned long long *d_keys = (unsigned long long *)b;
         int *d_n = (int *)(b + o_n), *d_many = (int *)(b + o_flag);
         KTLVO_HIP(ctx, hipMemsetAsync(b + o_flag, 0, o_cp - o_flag, ctx->stream)); // the flag and, if used, the cells' counts
         if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
-        hipLaunchKernelGGL(corner_sort_frames, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand,
-                           s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, (size_t)SORT_CAP, d_many);
+        hipLaunchKernelGGL(corner_sort_frames<false>, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand,
+                           s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, (size_t)SORT_CAP, d_many, (const SortPlan *)nullptr);
         KTLVO_HIP(ctx, hipGetLastError());
         if (!dist) {
             hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys,
@@ -1781,19 +1980,28 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     const size_t o_keys = 0, o_n = o_keys + up(np2 * 8 * n_frames), o_cc = o_n + up(4 * (size_t)n_frames);
     const size_t o_cp = o_cc + up(cells * 4 * n_frames), o_rounds = o_cp + up(cells * 16 * n_frames);
     const bool rounds = global_grid && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_MAX;
-    const size_t total = o_rounds + (rounds ? rounds_work_bytes(np2, cells, n_frames) : 0);
+    const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(np2, cells, n_frames) : 0);
+    const size_t total = o_bucket + bucket_work_bytes(n_frames);
     rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream)); // keys, counters
-    const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
-    hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
-                       p->quality, d_keys, d_n, area, np2);
-    KTLVO_HIP(ctx, hipGetLastError());
-    rc = sort_keys(ctx, d_keys, np2, n_frames, d_n);
-    if (rc != KTLVO_OK) return rc;
+    bool sorted = false;
+    if (ctx->frames_lds_sort) { // by response ranges in LDS
+        rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, np2, n_frames, n_sup, b + o_bucket, h_many,
+                         &sorted);
+        if (rc != KTLVO_OK) return rc;
+    }
+    if (!sorted) {
+        KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream)); // keys, counters
+        const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
+        hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
+                           p->quality, d_keys, d_n, area, np2);
+        KTLVO_HIP(ctx, hipGetLastError());
+        rc = sort_keys(ctx, d_keys, np2, n_frames, d_n);
+        if (rc != KTLVO_OK) return rc;
+    }
     if (!dist) {
         hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys, d_n,
                            roi.w, limit, d_xy, d_resp, d_counts, np2, (size_t)cap);

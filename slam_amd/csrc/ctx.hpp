@@ -99,10 +99,10 @@ struct ktlvo_ctx {
     size_t misc_bytes = 0;
     bool frame_chain = true;    // the frame path's six tracks from one launch (KTLVO_FRAME_PER_STAGE=1 at creation: a launch per stage)
     bool pyr_per_level = false; // one pyrDown launch per level instead of the fused small-level kernel (A/B, tests)
-    bool big_lds_select = false, big_lds_sort = false; // corner kernels that use more than 64 KiB of LDS have been enabled
+    bool big_lds_select = false, big_lds_sort = false, big_lds_sort_buckets = false; // corner kernels that use more than 64 KiB of LDS have been enabled
     bool candidates_wave = true; // large ROIs take corner_candidates_wave (KTLVO_CANDIDATES_TILES=1 at creation: the LDS-tile kernel; A/B, tests)
     bool greedy_rounds = true;   // frames whose cell grid does not fit LDS take the greedy pass in rounds (KTLVO_GREEDY_SEQUENTIAL=1 at creation: a workgroup per frame walks the candidates; A/B, tests)
-    bool frames_lds_sort = true; // batched detection sorts each frame in LDS (KTLVO_FRAMES_GLOBAL_SORT=1 at creation: A/B, tests)
+    bool frames_lds_sort = true; // whole frames are sorted in LDS, one workgroup per frame or per response range of a frame (KTLVO_FRAMES_GLOBAL_SORT=1 at creation: the bitonic network in global memory; A/B, tests)
     void *noalloc_scratch = nullptr; // this device's address of the fixed scratch array of ktlvo_detect_gftt_noalloc
     void *d_frames_out = nullptr; // results of ktlvo_detect_gftt_frames before they go home
     size_t frames_out_bytes = 0;

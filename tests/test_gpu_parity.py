@@ -458,6 +458,40 @@ def test_greedy_pass_in_rounds_equals_sequential_pass(make_ctx, oracle, klib):
     assert len(a[4][0]) == 0
 
 
+def test_sort_by_response_ranges_equals_global_sort(make_ctx, oracle, klib):
+    """Frames with more keys above the threshold than one workgroup sorts (here 20,000 to 170,000) are sorted by ranges
+    of the response, a workgroup per range; a context created with KTLVO_FRAMES_GLOBAL_SORT=1 runs the bitonic network
+    in global memory.  Same corners, order and responses, per call and for a batch; a frame of few distinct responses
+    (tens of thousands of equal keys in one bin) is turned down by the plan and takes the global sort in both; against
+    the oracle for one frame."""
+    W, H = 1600, 900
+    rng = np.random.default_rng(77)
+    imgs = [synth.texture_image(W, H, seed=190 + i, periods=(13.0, 6.0, 4.0), noise=True) for i in range(2)]
+    imgs.append(rng.integers(0, 256, (H, W), dtype=np.uint8))
+    yy, xx = np.mgrid[0:H, 0:W]
+    imgs.append((((xx // 3 + yy // 3) % 2) * 200).astype(np.uint8)) # a checkerboard of 3 x 3 squares: equal responses
+    n = len(imgs)
+    lds = make_ctx(width=W, height=H, num_slots=n, max_points=60000)
+    os.environ["KTLVO_FRAMES_GLOBAL_SORT"] = "1"
+    try:
+        glob = make_ctx(width=W, height=H, num_slots=n, max_points=60000)
+    finally:
+        del os.environ["KTLVO_FRAMES_GLOBAL_SORT"]
+    for ctx in (lds, glob):
+        ctx.upload_images(list(range(n)), np.stack(imgs))
+    for gp, frames in ((klib.gftt_params(60000, 0.001, 2.0, 3, 0, 0.0), [0, 1, 2]), (klib.gftt_params(8000, 0.01, 6.0, 3, 0, 0.0), [2, 0]),
+                       (klib.gftt_params(60000, 0.0005, 0.0, 3, 1, 0.04), [1, 2]), (klib.gftt_params(30000, 0.01, 3.0, 3, 0, 0.0), [0, 3, 1])):
+        a = lds.detect_gftt_frames(frames, gp)
+        b = glob.detect_gftt_frames(frames, gp)
+        for f, (xa, ra), (xb, rb) in zip(frames, a, b):
+            assert np.array_equal(xa, xb) and np.array_equal(ra, rb), (f, gp.max_corners, gp.min_dist, len(xa), len(xb))
+        (xa, ra), = lds.detect_gftt(frames[0], [(0, 0, W, H)], gp)
+        assert np.array_equal(xa, a[0][0]) and np.array_equal(ra, a[0][1]), (frames[0], gp.min_dist)
+        f = frames[-1]
+        oxy, oresp = oracle.good_features(imgs[f], None, gp.max_corners, gp.quality, gp.min_dist, bool(gp.use_harris), gp.harris_k)
+        assert np.array_equal(a[-1][0], np.asarray(oxy, np.float32).reshape(-1, 2)) and np.array_equal(a[-1][1], np.asarray(oresp, np.float32))
+
+
 def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
     g = np.load(os.path.join(GOLD, "corners_260x180.npz"))
     ctx = make_ctx(width=260, height=180)
