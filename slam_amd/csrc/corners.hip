@@ -1297,6 +1297,7 @@ struct LfArgs {
     uint2 *items;                   // candidates in cell order: (x | y << 16, rank)
     int *blk_cnt;                   // accepted candidates per block of 1024 ranks
     int *flags;                     // [round * n_frames + f]: the launch left a candidate of the frame undecided
+    int *unsettled; int last_round; // launch number last_round raises *unsettled as well (launches queued without looking at the flags)
     int cell, gw, gh, scan_blocks;
     double min_dist;
     int limit;
@@ -1307,8 +1308,8 @@ struct LfArgs {
 };
 constexpr int LF_SCAN = 4096;        // cells per workgroup of the scan
 constexpr int LF_SCAN_BLOCKS = 1024; // at most: grids of up to 4M cells
-constexpr int LF_PEND = 12;          // undecided predecessors a candidate keeps track of within a launch
-constexpr int LF_TRIES = 48;         // times it looks at them again before it leaves the rest to the next launch
+constexpr int LF_PEND = 24;          // undecided predecessors a candidate keeps track of within a launch
+constexpr int LF_TRIES = 64;         // times it looks at them again before it leaves the rest to the next launch
 __global__ __launch_bounds__(256) void lf_count(LfArgs a) {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_ptr[f]) return;
@@ -1447,7 +1448,10 @@ __global__ __launch_bounds__(256) void lf_round(LfArgs a, int round) {
         settle();
         if (lost && !rejected && npend == 0) break; // predecessors it could not keep: the next launch
     }
-    if (!done) a.flags[round * a.n_frames + f] = 1;
+    if (!done) {
+        a.flags[round * a.n_frames + f] = 1;
+        if (round == a.last_round) *a.unsettled = 1;
+    }
 }
 __global__ __launch_bounds__(1024) void lf_block_counts(LfArgs a) {
     const int f = blockIdx.y, i = blockIdx.x * 1024 + threadIdx.x;
@@ -1709,12 +1713,17 @@ static int launch_select_large(ktlvo_ctx *ctx, const SelLargeArgs &a, int n_rois
 // The greedy pass in rounds over n_frames sorted key lists (np2 keys apart, n_sup bounds every list's length): work
 // memory `work` of rounds_work_bytes(), h_flags = n_frames pinned ints.  After every launch of the relaxation the host
 // looks whether any frame still has an undecided candidate; one launch is the rule.  Returns KTLVO_ERR_STATE for the
-// caller to take the sequential pass if 32 launches have not settled a frame.
+// caller to take the sequential pass if 32 launches have not settled a frame.  With queued > 0 that many launches are
+// queued and the output written without a look at the flags (n_sup and np2 may then be bounds instead of counts the
+// host has fetched); the last of them raises *d_unsettled if it leaves a candidate undecided, which the caller reads
+// when it next waits for the stream, and then does the frames again another way.
 constexpr int LF_MAX_ROUNDS = 32;
 // The sequential pass takes a workgroup per frame and as long for 200 frames as for one; the relaxation uses the whole
 // chip and takes as long as its frames add up to.  Measured on 1920 x 1080 and 3840 x 2160 frames the two meet at
 // about 50 frames per call.
 constexpr int LF_FRAMES_MAX = 48;
+constexpr int LF_FRAMES_QUEUED_MAX = 16; // the same for frames whose grid fits LDS (a faster sequential pass): measured on 1241 x 376 frames
+constexpr int LF_QUEUED = 2;             // launches of the relaxation queued without looking at the flags
 static size_t lf_cells_stride(size_t cells) { return (cells + 1 + 3) & ~(size_t)3; }
 static bool rounds_possible(size_t cells) { return (lf_cells_stride(cells) + LF_SCAN - 1) / LF_SCAN <= (size_t)LF_SCAN_BLOCKS; }
 static size_t rounds_work_bytes(size_t np2, size_t cells, int n_frames) {
@@ -1723,7 +1732,8 @@ static size_t rounds_work_bytes(size_t np2, size_t cells, int n_frames) {
     return up(np2 * F) + up(np2 * 8 * F) + 2 * up(cs * 4 * F) + up(cs * 4 * F) + up((size_t)LF_SCAN_BLOCKS * 4 * F) +
            up((np2 / 1024 + 1) * 4 * F) + up((size_t)LF_MAX_ROUNDS * F * 4);
 }
-static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *work, int *h_flags) {
+static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *work, int *h_flags, int queued = 0,
+                      int *d_unsettled = nullptr) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t F = (size_t)a.n_frames, cs = lf_cells_stride((size_t)a.gw * a.gh);
     a.keys_stride = np2; a.cells_stride = cs; a.blk_stride = np2 / 1024 + 1;
@@ -1738,14 +1748,16 @@ static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *wor
     a.blk_cnt = (int *)w; w += up(a.blk_stride * 4 * F);
     a.flags = (int *)w;
     KTLVO_HIP(ctx, hipMemsetAsync(a.cell_cnt, 0, 2 * up(cs * 4 * F), ctx->stream)); // counts and handed-out places
-    KTLVO_HIP(ctx, hipMemsetAsync(a.flags, 0, (size_t)LF_MAX_ROUNDS * F * 4, ctx->stream));
+    a.last_round = queued - 1; a.unsettled = queued ? d_unsettled : a.flags;
+    if (!queued) KTLVO_HIP(ctx, hipMemsetAsync(a.flags, 0, (size_t)LF_MAX_ROUNDS * F * 4, ctx->stream));
     const dim3 g256((unsigned)((n_sup + 255) / 256), (unsigned)F), g1024((unsigned)((n_sup + 1023) / 1024), (unsigned)F);
     hipLaunchKernelGGL(lf_count, g256, dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(lf_scan_cells, dim3((unsigned)a.scan_blocks, (unsigned)F), dim3(1024), 0, ctx->stream, a);
     hipLaunchKernelGGL(lf_scan_blocks, dim3((unsigned)F), dim3(1024), 0, ctx->stream, a);
     hipLaunchKernelGGL(lf_fill, g256, dim3(256), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
-    bool settled = false;
+    bool settled = queued > 0;
+    for (int r = 0; r < queued; r++) hipLaunchKernelGGL(lf_round, g256, dim3(256), 0, ctx->stream, a, r);
     for (int r = 0; r < LF_MAX_ROUNDS && !settled; r++) {
         hipLaunchKernelGGL(lf_round, g256, dim3(256), 0, ctx->stream, a, r);
         KTLVO_HIP(ctx, hipGetLastError());
@@ -1840,7 +1852,8 @@ static bool lds_sort_likely(size_t area) { return area <= ((size_t)512 << 10); }
 // The same for a list of large ROIs without a word from the device in between: every ROI's keys are filtered and sorted
 // in LDS by one workgroup (corner_sort_frames), then its greedy pass runs; the ROIs take turns on one work area, in
 // stream order.  *d_many_out is a device flag that is raised when some ROI had more keys above its threshold than the
-// LDS sort holds; the caller looks at it once everything has run and then takes select_large for the whole list.
+// LDS sort holds, or candidates the queued launches of the relaxation left undecided; the caller looks at it once
+// everything has run and then takes select_large for the whole list.
 static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const ktlvo_gftt_params *p, const CornerScratch &s,
                             float *d_xy, float *d_resp, int *d_counts, int cap, int **d_many_out) {
     const bool dist = p->min_dist >= 1;
@@ -1852,7 +1865,13 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         if (!grid_fits_lds(cell, gw, gh)) cells_max = std::max(cells_max, (size_t)gw * gh);
     }
     const size_t o_n = up((size_t)SORT_CAP * 8), o_flag = o_n + 256, o_cc = o_flag + 256, o_cp = o_cc + up(cells_max * 4);
-    int rc = ensure_aux(ctx, o_cp + up(cells_max * 16));
+    const size_t o_rounds = o_cp + up(cells_max * 16);
+    size_t rounds_bytes = 0; // the greedy pass as a relaxation, two launches queued blind, where the grid allows it
+    for (int r = 0; r < n_roi && dist && ctx->greedy_rounds; r++) {
+        const size_t cells = (size_t)((rois[r].w + cell - 1) / cell) * ((rois[r].h + cell - 1) / cell);
+        if (rounds_possible(cells)) rounds_bytes = std::max(rounds_bytes, rounds_work_bytes(SORT_CAP, cells, 1));
+    }
+    int rc = ensure_aux(ctx, o_rounds + rounds_bytes);
     if (rc != KTLVO_OK) return rc;
     rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
     if (rc != KTLVO_OK) return rc;
@@ -1880,6 +1899,14 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
         a.xy = xy; a.resp = resp; a.count = d_counts + r; a.overflow = s.d_overflow;
         a.keys_stride = a.cells_stride = a.out_stride = 0;
+        if (ctx->greedy_rounds && rounds_possible((size_t)a.gw * a.gh)) {
+            LfArgs l;
+            l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = a.gw; l.gh = a.gh; l.min_dist = p->min_dist; l.limit = limit;
+            l.xy = xy; l.resp = resp; l.count = d_counts + r; l.out_stride = 0; l.n_frames = 1;
+            rc = run_rounds(ctx, l, SORT_CAP, SORT_CAP, b + o_rounds, nullptr, LF_QUEUED, d_many);
+            if (rc != KTLVO_OK) return rc;
+            continue;
+        }
         if (!select_uses_lds_grid(a)) {
             KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, (size_t)a.gw * a.gh * 4, ctx->stream));
             KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, (size_t)a.gw * a.gh * 16, ctx->stream));
@@ -1936,7 +1963,11 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         // keys than the LDS sort holds; then, and only then, the global path below does the batch again.
         const size_t o_n = up((size_t)SORT_CAP * 8 * n_frames), o_flag = o_n + up(4 * (size_t)n_frames), o_cc = o_flag + 256;
         const size_t o_cp = o_cc + (global_grid ? up(cells * 4 * n_frames) : 0);
-        const size_t total = o_cp + (global_grid ? up(cells * 16 * n_frames) : 0);
+        const size_t o_rounds = o_cp + (global_grid ? up(cells * 16 * n_frames) : 0);
+        // few frames: the greedy pass as a relaxation, two launches queued blind (a frame they do not settle raises
+        // the same flag as one with too many keys)
+        const bool rounds = dist && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_QUEUED_MAX;
+        const size_t total = o_rounds + (rounds ? rounds_work_bytes(SORT_CAP, cells, n_frames) : 0);
         rc = ensure_aux(ctx, total);
         if (rc != KTLVO_OK) return rc;
         rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
@@ -1956,7 +1987,14 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         } else {
             a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = (size_t)SORT_CAP;
             a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
-            rc = launch_select_large(ctx, a, n_frames);
+            if (rounds) {
+                LfArgs l;
+                l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
+                l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
+                rc = run_rounds(ctx, l, SORT_CAP, SORT_CAP, b + o_rounds, nullptr, LF_QUEUED, d_many);
+            } else {
+                rc = launch_select_large(ctx, a, n_frames);
+            }
             if (rc != KTLVO_OK) return rc;
         }
         KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));

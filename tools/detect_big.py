@@ -1,10 +1,10 @@
 """Batched whole-frame detection on big frames, for timing and kernel traces:
-  python tools/detect_big.py 1080|4k [frames per call]   (default 31 frames of 1920x1080, 15 of 3840x2160)"""
+  python tools/detect_big.py 1080|4k|kitti [frames per call]   (default 31 frames of 1920x1080, 15 of 3840x2160, 16 of 1241x376)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from slam_amd import lib as K, synth
-W, H, nf, nc, md = (1920, 1080, 31, 8000, 5.0) if sys.argv[1] == "1080" else (3840, 2160, 15, 16384, 8.0)
+W, H, nf, nc, md = {"1080": (1920, 1080, 31, 8000, 5.0), "4k": (3840, 2160, 15, 16384, 8.0), "kitti": (1241, 376, 16, 2000, 10.0)}[sys.argv[1]]
 if len(sys.argv) > 2:
     nf = int(sys.argv[2])
 frames = synth.render_corridor_frames(W, H, 0x5EED0002, 4, workers=4)
