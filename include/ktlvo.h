@@ -159,8 +159,10 @@ int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi
 /* cv::goodFeaturesToTrack on the same region of n_frames slots in one call (roi NULL = the whole frame): what
  * featureTracking.cpp:102-103, 421-422 does per image, for a batch of images, as the frame-pair stream and
  * batch workloads need it (2000 to 16384 corners on whole frames).  Every kernel of the whole-frame path takes the
- * frame from its grid, so the batch costs three launches (candidates, a sort and a greedy pass with a workgroup per
- * frame each); per frame the result is ktlvo_detect_gftt's for that slot and region.
+ * frame from its grid, so a batch of KITTI-sized frames costs three launches (candidates, a sort and a greedy pass
+ * with a workgroup per frame each); up to 16 such frames, or up to 48 larger ones, take the greedy pass as a parallel
+ * relaxation over all candidates instead, and frames with more than 16384 corners above the threshold are sorted by
+ * ranges of the response.  Per frame the result is ktlvo_detect_gftt's for that slot and region whatever the route.
  * Outputs [n_frames][cap][2], [n_frames][cap], [n_frames]. */
 int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi,
                              const ktlvo_gftt_params *params, float *xy, float *response, int *counts, int cap);
