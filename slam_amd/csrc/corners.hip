@@ -1410,14 +1410,17 @@ __global__ __launch_bounds__(256) void lf_round(LfArgs a, int round) {
         for (int j = 0; j < 4; j++) head[r][j] = items[min(k0[r] + j, n - 1)];
     bool rejected = false, lost = false;
     int npend = 0;
+    // the stronger candidates within reach are collected first and their states read afterwards, several at a time
+    // (a read followed by a branch on its value would make every one of them wait for the one before)
     auto look = [&](uint2 it) {
         const int q = (int)it.y;
         if (q >= i) return;
         const float dx = (float)(x - (int)(it.x & 0xffffu)), dy = (float)(y - (int)(it.x >> 16));
         if (!(fabsf(dx) < md && fabsf(dy) < md && (double)(dx * dx + dy * dy) < md2)) return;
-        const unsigned char sq = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (npend < LF_PEND) { pend[npend++] = q; return; }
+        const unsigned char sq = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // no room: looked at once
         if (sq == 1) rejected = true;
-        else if (sq == 0) { if (npend < LF_PEND) pend[npend++] = q; else lost = true; }
+        else if (sq == 0) lost = true;
     };
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -1429,24 +1432,25 @@ __global__ __launch_bounds__(256) void lf_round(LfArgs a, int round) {
     // A decision is published the moment it is made, inside the loop: lanes of one wave that wait for each other
     // would otherwise only see it once the whole wave has left the loop.
     bool done = false;
-    auto settle = [&]() {
+    for (int t = 0; t <= LF_TRIES && !done; t++) {
+        if (t) __builtin_amdgcn_s_sleep(2);
+        int keep = 0;
+        for (int k = 0; k < npend; k += 4) {
+            unsigned char sq[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                sq[j] = k + j < npend ? __hip_atomic_load(&state[pend[k + j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned char)2;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (sq[j] == 1) rejected = true;
+                else if (sq[j] == 0) pend[keep++] = pend[k + j]; // keep <= k + j: nothing not yet read is overwritten
+            }
+        }
+        npend = keep;
         if (rejected) __hip_atomic_store(&state[i], (unsigned char)2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else if (npend == 0 && !lost) __hip_atomic_store(&state[i], (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         done = rejected || (npend == 0 && !lost);
-    };
-    settle();
-    for (int t = 0; t < LF_TRIES && !done; t++) {
-        __builtin_amdgcn_s_sleep(4);
-        int keep = 0;
-        for (int k = 0; k < npend; k++) {
-            const int q = pend[k];
-            const unsigned char sq = __hip_atomic_load(&state[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (sq == 1) { rejected = true; break; }
-            if (sq == 0) pend[keep++] = q;
-        }
-        npend = keep;
-        settle();
-        if (lost && !rejected && npend == 0) break; // predecessors it could not keep: the next launch
+        if (lost && npend == 0) break; // predecessors it could not keep: the next launch
     }
     if (!done) {
         a.flags[round * a.n_frames + f] = 1;
