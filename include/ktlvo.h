@@ -167,9 +167,10 @@ int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi
 int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi,
                              const ktlvo_gftt_params *params, float *xy, float *response, int *counts, int cap);
 /* The same with DEVICE output arrays: corners go straight into ktlvo_pyrlk_batch_dev without a trip through
- * host memory.  The whole detection is queued in one go and the call waits for it once, at its end (it has to
- * learn whether some frame had more keys than the per-frame sort holds and must go through the global sort
- * instead), so the arrays are complete when it returns. */
+ * host memory.  The arrays are written in the order of the context's stream, so any later call on the context
+ * finds them complete.  (The call itself waits for the device once or twice: at its end, to learn whether the
+ * route it queued blind stands or a frame has to go through the global sort instead, and for frames with more
+ * than 512K pixels before that for the candidate counts that size its lists.) */
 int ktlvo_detect_gftt_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi,
                                  const ktlvo_gftt_params *params, float *d_xy, float *d_response, int *d_counts, int cap);
 /* The same detection for callers that must not allocate (code under HIP graph capture, tight serving

@@ -74,7 +74,7 @@ __global__ void corner_setup(RoiTable t, int n_roi, RoiDev *rois, unsigned *roi_
         roi_max[i] = 0u;
         cand_cnt[i] = 0;
     }
-    if (i == 0) *overflow = 0;
+    if (i == 0) { overflow[0] = 0; overflow[1] = 0; } // [1]: a blind route asks for the call to be done again the other way
 }
 
 __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, int slot, const RoiDev *rois, float s1,
@@ -1572,7 +1572,7 @@ static int corner_scratch_setup(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, c
     KTLVO_HIP(ctx, hipMemcpyAsync(s.d_rois, rois, sizeof(RoiDev) * n_roi, hipMemcpyHostToDevice, ctx->stream));
     KTLVO_HIP(ctx, hipMemsetAsync(s.d_max, 0, 4 * (size_t)n_roi, ctx->stream));
     KTLVO_HIP(ctx, hipMemsetAsync(s.d_cnt, 0, 4 * (size_t)n_roi, ctx->stream));
-    KTLVO_HIP(ctx, hipMemsetAsync(s.d_overflow, 0, 4, ctx->stream));
+    KTLVO_HIP(ctx, hipMemsetAsync(s.d_overflow, 0, 8, ctx->stream));
     return KTLVO_OK;
 }
 
@@ -1671,17 +1671,19 @@ static int allow_big_lds(ktlvo_ctx *ctx, K kernel, size_t bytes, bool &done) {
 // corner_sort_frames<true>).  n_sup = the largest candidate count, d_work = n_lists plans, a flag and n_lists
 // histograms (bucket_work_bytes), h_flag = one pinned int.  *sorted says whether out[] (lists out_stride keys apart) and out_cnt[]
 // are now what cand_filter and sort_keys would have left at the lists' fronts; if not (a list the plan turned down),
-// the caller takes those two.
+// the caller takes those two.  With d_redo the call does not wait: a plan turned down raises *d_redo (and leaves its
+// list empty, so whatever is queued behind does nothing with it), and the caller finds out when it next waits.
 static size_t bucket_plans_bytes(int n_lists) { return (sizeof(SortPlan) * (size_t)n_lists + 255) & ~(size_t)255; }
 static size_t bucket_work_bytes(int n_lists) { return bucket_plans_bytes(n_lists) + 256 + (size_t)n_lists * PLAN_BINS * 4; }
 static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const int *d_cnt, const unsigned *d_max, double quality,
                        unsigned long long *d_out, int *d_out_cnt, size_t cand_stride, size_t out_stride, int n_lists, int n_sup,
-                       char *d_work, int *h_flag, bool *sorted) {
+                       char *d_work, int *h_flag, bool *sorted, int *d_redo = nullptr) {
     SortPlan *d_plans = (SortPlan *)d_work;
-    int *d_flag = (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_flag + 64;
+    int *d_own = (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_own + 64;
+    int *d_flag = d_redo ? d_redo : d_own;
     int rc = allow_big_lds(ctx, corner_sort_frames<true>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort_buckets);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemsetAsync(d_flag, 0, 256 + (size_t)n_lists * PLAN_BINS * 4, ctx->stream)); // flag and histograms
+    KTLVO_HIP(ctx, hipMemsetAsync(d_own, 0, 256 + (size_t)n_lists * PLAN_BINS * 4, ctx->stream)); // flag and histograms
     const dim3 slices((unsigned)((n_sup + PLAN_SLICE - 1) / PLAN_SLICE), (unsigned)n_lists);
     hipLaunchKernelGGL(corner_sort_hist, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_hist);
     hipLaunchKernelGGL(corner_sort_plan, dim3((unsigned)n_lists), dim3(1024), 0, ctx->stream, (const int *)d_hist, d_max, quality,
@@ -1692,6 +1694,10 @@ static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const i
     hipLaunchKernelGGL(corner_sort_frames<true>, dim3((unsigned)n_lists, nb), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
                        d_cand, d_cnt, d_max, quality, d_out, d_out_cnt, cand_stride, out_stride, d_flag, (const SortPlan *)d_plans);
     KTLVO_HIP(ctx, hipGetLastError());
+    if (d_redo) { // the caller looks at the flag when it next waits for the stream
+        *sorted = true;
+        return KTLVO_OK;
+    }
     KTLVO_HIP(ctx, hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *sorted = *h_flag == 0;
@@ -1778,8 +1784,11 @@ static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *wor
 }
 
 // Sort + greedy pass of one large ROI on the device.  n_sup = the ROI's candidate count (already on the host).
+// blind: nothing waits for the device -- the sort by response ranges and two launches of the relaxation are queued, and
+// a plan turned down or a candidate left undecided raises the scratch's second flag (s.d_overflow[1]); the caller looks
+// at it when the results are home and then calls again with blind = false.
 static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, const ktlvo_gftt_params *p,
-                        const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap, int *h_flags) {
+                        const CornerScratch &s, float *d_xy, float *d_resp, int *d_count, int cap, int *h_flags, bool blind) {
     if (n_sup == 0) {
         KTLVO_HIP(ctx, hipMemsetAsync(d_count, 0, 4, ctx->stream));
         return KTLVO_OK;
@@ -1804,7 +1813,7 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     bool sorted = false;
     if (ctx->frames_lds_sort) { // by response ranges in LDS
         rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi, p->quality, d_keys, d_n, 0, 0, 1, n_sup, b + o_bucket,
-                         h_flags, &sorted);
+                         h_flags, &sorted, blind ? s.d_overflow + 1 : nullptr);
         if (rc != KTLVO_OK) return rc;
     }
     if (!sorted) {
@@ -1828,6 +1837,7 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
             LfArgs l;
             l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
             l.xy = d_xy; l.resp = d_resp; l.count = d_count; l.out_stride = 0; l.n_frames = 1;
+            if (blind && sorted) return run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1);
             rc = run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_flags);
             if (rc != KTLVO_ERR_STATE) return rc;
         }
@@ -2029,44 +2039,54 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)(b + o_keys);
     int *d_n = (int *)(b + o_n);
-    bool sorted = false;
-    if (ctx->frames_lds_sort) { // by response ranges in LDS
-        rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, np2, n_frames, n_sup, b + o_bucket, h_many,
-                         &sorted);
-        if (rc != KTLVO_OK) return rc;
-    }
-    if (!sorted) {
-        KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream)); // keys, counters
-        const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
-        hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
-                           p->quality, d_keys, d_n, area, np2);
-        KTLVO_HIP(ctx, hipGetLastError());
-        rc = sort_keys(ctx, d_keys, np2, n_frames, d_n);
-        if (rc != KTLVO_OK) return rc;
-    }
-    if (!dist) {
-        hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys, d_n,
-                           roi.w, limit, d_xy, d_resp, d_counts, np2, (size_t)cap);
-        KTLVO_HIP(ctx, hipGetLastError());
-    } else {
-        rc = KTLVO_ERR_STATE;
-        if (rounds) { // frames whose grid does not fit LDS: the relaxation over all candidates of all frames at once
-            LfArgs l;
-            l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
-            l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
-            rc = run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_many + 1);
-            if (rc != KTLVO_OK && rc != KTLVO_ERR_STATE) return rc;
-        }
-        if (rc == KTLVO_ERR_STATE) { // the sequential pass, a workgroup per frame
-            if (global_grid) {
-                KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, cells * 4 * n_frames, ctx->stream));
-                KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
-            }
-            a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = np2;
-            a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
-            rc = launch_select_large(ctx, a, n_frames);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // first without a word from the device (sort by response ranges, two launches of the relaxation; the scratch's
+        // second flag says at the end whether that stands), then, if it does not, step by step
+        const bool blind = attempt == 0 && ctx->frames_lds_sort && rounds;
+        bool sorted = false;
+        if (ctx->frames_lds_sort) { // by response ranges in LDS
+            rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, np2, n_frames, n_sup, b + o_bucket, h_many,
+                             &sorted, blind ? s.d_overflow + 1 : nullptr);
             if (rc != KTLVO_OK) return rc;
         }
+        if (!sorted) {
+            KTLVO_HIP(ctx, hipMemsetAsync(b, 0, o_cc, ctx->stream)); // keys, counters
+            const unsigned fblocks = (unsigned)std::min<size_t>(((size_t)n_sup + 255) / 256, 1024);
+            hipLaunchKernelGGL(cand_filter, dim3(fblocks, (unsigned)n_frames), dim3(256), 0, ctx->stream, s.d_cand, s.d_cnt, s.d_max,
+                               p->quality, d_keys, d_n, area, np2);
+            KTLVO_HIP(ctx, hipGetLastError());
+            rc = sort_keys(ctx, d_keys, np2, n_frames, d_n);
+            if (rc != KTLVO_OK) return rc;
+        }
+        if (!dist) {
+            hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys, d_n,
+                               roi.w, limit, d_xy, d_resp, d_counts, np2, (size_t)cap);
+            KTLVO_HIP(ctx, hipGetLastError());
+        } else {
+            rc = KTLVO_ERR_STATE;
+            if (rounds) { // frames whose grid does not fit LDS: the relaxation over all candidates of all frames at once
+                LfArgs l;
+                l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
+                l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
+                rc = blind ? run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1)
+                           : run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_many + 1);
+                if (rc != KTLVO_OK && rc != KTLVO_ERR_STATE) return rc;
+            }
+            if (rc == KTLVO_ERR_STATE) { // the sequential pass, a workgroup per frame
+                if (global_grid) {
+                    KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, cells * 4 * n_frames, ctx->stream));
+                    KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+                }
+                a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = np2;
+                a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
+                rc = launch_select_large(ctx, a, n_frames);
+                if (rc != KTLVO_OK) return rc;
+            }
+        }
+        if (!blind) break;
+        KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 8, hipMemcpyDeviceToHost, ctx->stream)); // (the second lands on h_many)
+        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!*h_many) return KTLVO_OK;
     }
     // the overflow flag lands in pinned memory behind the counts' mirror; a caller that waits for the stream reads it there
     KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2293,10 +2313,26 @@ extern "C" int ktlvo_detect_gftt(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois
         // the global sort is sized by the candidate counts, so they come home first
         KTLVO_HIP(ctx, hipMemcpyAsync(h_cnt, s.d_cnt, 4 * (size_t)n_roi, hipMemcpyDeviceToHost, ctx->stream));
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int r = 0; r < n_roi; r++) {
-            rc = select_large(ctx, rois[r], r, h_cnt[r], p, s, d_xy + (size_t)r * cap * 2, d_oresp + (size_t)r * cap,
-                              d_counts + r, cap, (int *)(hp + out_bytes + 4 * (size_t)n_roi + 8));
-            if (rc != KTLVO_OK) return rc;
+        int *h_two = (int *)(hp + out_bytes + 4 * (size_t)n_roi);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const bool blind = attempt == 0 && ctx->frames_lds_sort && ctx->greedy_rounds;
+            for (int r = 0; r < n_roi; r++) {
+                rc = select_large(ctx, rois[r], r, h_cnt[r], p, s, d_xy + (size_t)r * cap * 2, d_oresp + (size_t)r * cap,
+                                  d_counts + r, cap, h_two + 4, blind);
+                if (rc != KTLVO_OK) return rc;
+            }
+            if (!blind) break;
+            // blind: the results come home with the flag that says whether they stand
+            KTLVO_HIP(ctx, hipMemcpyAsync(hp, d_xy, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            KTLVO_HIP(ctx, hipMemcpyAsync(h_two, s.d_overflow, 8, hipMemcpyDeviceToHost, ctx->stream));
+            KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (!h_two[1]) {
+                memcpy(xy, hp, (size_t)n_roi * cap * 8);
+                memcpy(response, hp + (o_or - o_xy), (size_t)n_roi * cap * 4);
+                memcpy(counts, hp + (o_counts - o_xy), 4 * (size_t)n_roi);
+                if (h_two[0]) { ctx->last_error = "corner selection: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
+                return KTLVO_OK;
+            }
         }
     }
     // one copy home through pinned memory, then into the caller's three arrays
