@@ -18,7 +18,14 @@
 //                         over chunks of 512 candidates against a cell grid, which lives in LDS when it
 //                         fits and in global memory otherwise
 //   corner_sort_frames    a batch of frames: one workgroup per frame compacts and sorts the frame's keys
-//                         wholly in LDS (up to 16384 keys; the global sort takes over beyond)
+//                         wholly in LDS (up to 16384 keys)
+//   corner_sort_hist, _plan, _scatter, corner_sort_frames<true>
+//                         frames with more keys: the keys are split into ranges of the response of at most 16384
+//                         keys each, and every range is sorted in LDS by a workgroup of its own (the global sort
+//                         takes over for a frame with thousands of equal responses)
+//   lf_count ... lf_write the greedy pass as a relaxation over all candidates of a few frames at once (accepted once
+//                         every stronger candidate within reach is rejected, rejected once one is accepted) for
+//                         calls of few frames, where the walk's one workgroup per frame leaves the chip idle
 //
 // goodFeaturesToTrack thresholds the response map at quality * max (THRESH_TOZERO), dilates it 3x3 and
 // keeps pixels that equal the dilated value.  For a pixel above a non-negative threshold that is the
