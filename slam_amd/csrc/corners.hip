@@ -430,6 +430,7 @@ struct SelArgs {
     float *xy, *resp;
     int *counts;
     int *overflow;
+    int relax; // ROIs with up to 256 keys above the threshold take the greedy pass as a relaxation
 };
 
 // goodFeaturesToTrack's threshold for an ROI whose maximum response is maxVal: eig > maxVal * quality
@@ -498,10 +499,78 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
         if (tid == 0) { *a.overflow = 1; a.counts[roi] = -1; }
         return;
     }
+    const double md2 = a.min_dist * a.min_dist;
+    if (n <= 256 && a.relax) {
+        // Up to 256 keys above the threshold (the rule for the reference's sub-regions): the walk's result without
+        // the walk.  A candidate is accepted once every stronger candidate that the walk would test it against is
+        // rejected, and rejected once one of them is accepted.  Thread i owns candidate i: it finds the stronger ones
+        // within reach (in the nine cells around its own, as the walk's grid look-up) as a 256-bit mask in registers,
+        // and rounds over two 256-bit masks in LDS (accepted, rejected; a wave writes its 64 bits by ballot) settle
+        // everyone, one barrier per round; the accepted leave in rank order, the first `limit` of them.
+        __shared__ unsigned cxy[256];
+        __shared__ unsigned long long s_acc[4], s_rej[4];
+        const int lane = tid & 63, wv = tid >> 6;
+        const bool have = tid < n;
+        int x = 0, y = 0, xc = 0, yc = 0;
+        if (have) {
+            const unsigned idx = (unsigned)keys[tid];
+            x = idx & 0xffffu; y = idx >> 16; xc = x / cell; yc = y / cell;
+            cxy[tid] = (unsigned)xc | ((unsigned)yc << 16);
+        }
+        if (tid < 4) { s_acc[tid] = 0ull; s_rej[tid] = 0ull; }
+        __syncthreads();
+        unsigned long long pred[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w > wv) break; // only stronger candidates count: those of this wave's 64 and the waves' before
+            unsigned long long m = 0ull;
+            const int jend = n < (w + 1) * 64 ? n : (w + 1) * 64;
+            for (int j = w * 64; j < jend; j++) { // the same j in every lane: LDS broadcasts
+                const unsigned q = (unsigned)keys[j], qc = cxy[j];
+                const int ddx = xc - (int)(qc & 0xffffu), ddy = yc - (int)(qc >> 16);
+                const float dx = (float)x - (float)(q & 0xffffu), dy = (float)y - (float)(q >> 16);
+                const bool c = j < tid && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && (double)(dx * dx + dy * dy) < md2;
+                m |= (unsigned long long)c << (j & 63);
+            }
+            pred[w] = m;
+        }
+        int st = have ? 0 : 2; // 0 undecided, 1 accepted, 2 rejected (or no candidate)
+        for (int round = 0; round < 257; round++) { // the strongest undecided candidate decides in every round
+            if (st == 0) {
+                bool hit = false, clear = true;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    hit = hit || (pred[w] & s_acc[w]) != 0ull;
+                    clear = clear && (pred[w] & ~s_rej[w]) == 0ull;
+                }
+                st = hit ? 2 : clear ? 1 : 0;
+            }
+            // (a wave may write its words while another still reads the old ones: the masks only grow, and a
+            // decision made on an older mask is one made a round earlier)
+            const unsigned long long am = __ballot(st == 1), rm = __ballot(st == 2 && have);
+            if (lane == 0) { s_acc[wv] = am; s_rej[wv] = rm; }
+            if (!__syncthreads_or(st == 0)) break;
+        }
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const int c = __popcll(s_acc[w]);
+            before += w < wv ? c : 0;
+            total += c;
+        }
+        if (st == 1) {
+            const int pos = before + __popcll(s_acc[wv] & ((1ull << lane) - 1ull));
+            if (pos < limit) {
+                oxy[2 * pos] = (float)x; oxy[2 * pos + 1] = (float)y;
+                oresp[pos] = ord2f((unsigned)(keys[tid] >> 32));
+            }
+        }
+        if (tid == 0) a.counts[roi] = total < limit ? total : limit;
+        return;
+    }
     for (int i = tid; i < gw * gh; i += 256) cell_cnt[i] = 0;
     __syncthreads();
     if (tid >= 64) return; // the greedy pass is sequential over candidates; one wave runs it
-    const double md2 = a.min_dist * a.min_dist;
     volatile unsigned short *vcnt = cell_cnt;
     volatile unsigned(*vpts)[4] = cell_pts;
     const int nb = tid >> 2, slot = tid & 3; // lanes 0..35: 9 neighbour cells x 4 slots
@@ -1627,7 +1696,7 @@ static int corner_detect_small_dev(ktlvo_ctx *ctx, int slot, const RoiDev *rois,
     SelArgs a;
     a.rois = s.d_rois; a.cand = s.d_cand; a.cand_cnt = s.d_cnt; a.roi_max = s.d_max; a.quality = p->quality;
     a.max_corners = p->max_corners; a.cap = cap; a.min_dist = p->min_dist;
-    a.xy = d_xy; a.resp = d_resp; a.counts = d_counts; a.overflow = s.d_overflow;
+    a.xy = d_xy; a.resp = d_resp; a.counts = d_counts; a.overflow = s.d_overflow; a.relax = ctx->greedy_rounds;
     hipLaunchKernelGGL(corner_select, dim3(n_roi), dim3(256), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;

@@ -493,6 +493,37 @@ def test_sort_by_response_ranges_equals_global_sort(make_ctx, oracle, klib):
         assert np.array_equal(a[-1][0], np.asarray(oxy, np.float32).reshape(-1, 2)) and np.array_equal(a[-1][1], np.asarray(oresp, np.float32))
 
 
+def test_sub_region_relaxation_equals_walk(make_ctx, oracle, klib):
+    """Sub-regions with up to 256 keys above the threshold take the greedy pass as a relaxation inside their workgroup;
+    with more keys, or in a context created with KTLVO_GREEDY_SEQUENTIAL=1, one wave walks the sorted keys.  A grid of the
+    reference's 59 x 39 regions on a textured frame, regions of a noise patch with 100 to 500 keys, thin and one-pixel
+    regions; minimum distances 1 to 10 and 2.5 (a cell narrower than the distance), limits that cut early and not at
+    all: both contexts and the oracle agree per region."""
+    W, H = 640, 360
+    rng = np.random.default_rng(5150)
+    img = synth.texture_image(W, H, seed=321, periods=(23.0, 9.0, 5.0), noise=True)
+    img[200:300, 400:520] = rng.integers(0, 256, (100, 120), dtype=np.uint8)
+    rois = [(10 + 62 * j, 8 + 42 * i, 59, 39) for i in range(4) for j in range(6)]
+    rois += [(400, 200, 64, 64), (410, 210, 40, 30), (430, 220, 24, 20), (400, 200, 120, 34), (5, 5, 1, 1), (7, 300, 3, 50), (300, 350, 200, 4)]
+    relax = make_ctx(width=W, height=H)
+    os.environ["KTLVO_GREEDY_SEQUENTIAL"] = "1"
+    try:
+        walk = make_ctx(width=W, height=H)
+    finally:
+        del os.environ["KTLVO_GREEDY_SEQUENTIAL"]
+    for ctx in (relax, walk):
+        ctx.upload_image(0, img)
+    for gp in (klib.gftt_params(100, 0.01, 10.0, 3, 1, 0.04), klib.gftt_params(5, 0.01, 4.0, 3, 0, 0.0),
+               klib.gftt_params(400, 0.001, 1.0, 3, 0, 0.0), klib.gftt_params(400, 0.001, 2.5, 3, 0, 0.0),
+               klib.gftt_params(60, 0.05, 2.0, 3, 1, 0.04)):
+        a = relax.detect_gftt(0, rois, gp)
+        b = walk.detect_gftt(0, rois, gp)
+        for r, ((xa, ra), (xb, rb)) in enumerate(zip(a, b)):
+            assert np.array_equal(xa, xb) and np.array_equal(ra, rb), (rois[r], gp.max_corners, gp.min_dist, len(xa), len(xb))
+            oxy, oresp = oracle.good_features(img, rois[r], gp.max_corners, gp.quality, gp.min_dist, bool(gp.use_harris), gp.harris_k)
+            assert np.array_equal(xa, np.asarray(oxy, np.float32).reshape(-1, 2)) and np.array_equal(ra, np.asarray(oresp, np.float32)), (rois[r], gp.min_dist)
+
+
 def test_gftt_rois_match_oracle_and_golden(make_ctx, oracle, klib):
     g = np.load(os.path.join(GOLD, "corners_260x180.npz"))
     ctx = make_ctx(width=260, height=180)
