@@ -819,12 +819,16 @@ __device__ __forceinline__ void sort_stage(u64 *sk, int t, int np2, u64 (&k)[16]
 // ("buckets") of at most SORT_CAP keys, each sorted by a workgroup of its own behind the stronger ones.  Four launches:
 // corner_sort_hist counts the keys in PLAN_BINS bins of equal width in the responses' ordered integer form, strongest
 // first (a workgroup per PLAN_SLICE candidates: histogram in LDS, then added to the frame's in global memory);
-// corner_sort_plan (a workgroup per frame) cuts the row of bins wherever the running count passes a multiple of PLAN_T
-// -- a bucket then holds fewer than PLAN_T keys plus one bin's, which is why a bin with more than SORT_CAP - PLAN_T
-// keys (thousands of equal responses) sends the call to the global sort, as do more than SORT_MAXB buckets;
+// corner_sort_plan (a workgroup per frame) cuts the row of bins wherever the running count passes a multiple of T, the
+// frame's bucket size -- a bucket then holds fewer than T keys plus one bin's, which is why a bin with more than
+// SORT_CAP - T keys (thousands of equal responses) sends the call to the global sort.  T is the frame's key count over
+// the number of buckets wanted (PLAN_BUCKETS for a frame on its own: short sorts side by side where most of the chip
+// is idle anyway; a compute unit's worth per frame for a batch), within PLAN_T_MIN ... PLAN_T_MAX, and never more than
+// SORT_MAXB buckets;
 // corner_sort_scatter moves every key into its bucket's stretch of the output (a workgroup per PLAN_SLICE candidates
 // claims a run of places per bucket); corner_sort_frames<true> sorts each stretch where it lies.
-constexpr int PLAN_BINS = 8192, PLAN_T = 7680, SORT_MAXB = 63, PLAN_SLICE = 16384;
+constexpr int PLAN_BINS = 8192, SORT_MAXB = 63, PLAN_SLICE = 16384;
+constexpr int PLAN_BUCKETS = 48, PLAN_T_MIN = 1792, PLAN_T_MAX = 7680;
 struct SortPlan {
     unsigned max_ord;
     int shift, nb, total;
@@ -872,8 +876,9 @@ __global__ __launch_bounds__(1024) void corner_sort_hist(const unsigned long lon
         if (c) atomicAdd(&g_hist[(size_t)f * PLAN_BINS + i], c);
     }
 }
+// (max_total: the most keys a list may have for what is queued behind; more raises *too_many as well)
 __global__ __launch_bounds__(1024) void corner_sort_plan(const int *g_hist, const unsigned *roi_max, double quality, SortPlan *plans,
-                                                         int *out_cnt, int *too_many) {
+                                                         int *out_cnt, int *too_many, int max_total, int buckets_wanted) {
     __shared__ int pre[PLAN_BINS];
     __shared__ int s_wave[16], s_first[SORT_MAXB + 2], s_maxbin;
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -889,24 +894,22 @@ __global__ __launch_bounds__(1024) void corner_sort_plan(const int *g_hist, cons
     int total;
     int e = wg_scan_1024(sum, s_wave, &total);
     if (mx > 0) atomicMax(&s_maxbin, mx);
-    // a bin's bucket is the running count before it over PLAN_T; the first bin of a bucket is the lowest that has it
+    int T = (total + buckets_wanted - 1) / buckets_wanted;
+    T = T < PLAN_T_MIN ? PLAN_T_MIN : T > PLAN_T_MAX ? PLAN_T_MAX : T;
+    // a bin's bucket is the running count before it over T; the first bin of a bucket is the lowest that has it
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         pre[tid * 8 + j] = e;
-        if (c[j] > 0 && e / PLAN_T <= SORT_MAXB) atomicMin(&s_first[e / PLAN_T], tid * 8 + j);
+        if (c[j] > 0 && e / T <= SORT_MAXB) atomicMin(&s_first[e / T], tid * 8 + j);
         e += c[j];
     }
     __syncthreads();
-    const int nb = total > 0 ? (total - 1) / PLAN_T + 1 : 0;
-    const bool bad = nb > SORT_MAXB || s_maxbin > SORT_CAP - PLAN_T;
-    if (tid == 0) { // buckets no bin starts in are empty: they begin where the next one does
-        for (int b = SORT_MAXB; b >= 0; --b)
-            if (s_first[b] == PLAN_BINS) s_first[b] = s_first[b + 1];
-    }
-    __syncthreads();
+    const int nb = total > 0 ? (total - 1) / T + 1 : 0;
+    const bool bad = nb > SORT_MAXB || s_maxbin > SORT_CAP - T || total > max_total;
     SortPlan &P = plans[f];
     if (tid <= SORT_MAXB) {
-        const int fb = s_first[tid];
+        int fb = PLAN_BINS; // buckets no bin starts in are empty: they begin where the next one does
+        for (int b = tid; b <= SORT_MAXB; b++) fb = min(fb, s_first[b]);
         P.first_bin[tid] = fb;
         P.off[tid] = fb == PLAN_BINS ? total : pre[fb];
         P.cursor[tid] = 0;
@@ -1748,12 +1751,13 @@ static int allow_big_lds(ktlvo_ctx *ctx, K kernel, size_t bytes, bool &done) {
 // histograms (bucket_work_bytes), h_flag = one pinned int.  *sorted says whether out[] (lists out_stride keys apart) and out_cnt[]
 // are now what cand_filter and sort_keys would have left at the lists' fronts; if not (a list the plan turned down),
 // the caller takes those two.  With d_redo the call does not wait: a plan turned down raises *d_redo (and leaves its
-// list empty, so whatever is queued behind does nothing with it), and the caller finds out when it next waits.
+// list empty, so whatever is queued behind does nothing with it), and the caller finds out when it next waits; n_sup
+// may then be a bound (the ROI's area) and max_total says how many keys above the threshold out[] has room for.
 static size_t bucket_plans_bytes(int n_lists) { return (sizeof(SortPlan) * (size_t)n_lists + 255) & ~(size_t)255; }
 static size_t bucket_work_bytes(int n_lists) { return bucket_plans_bytes(n_lists) + 256 + (size_t)n_lists * PLAN_BINS * 4; }
 static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const int *d_cnt, const unsigned *d_max, double quality,
                        unsigned long long *d_out, int *d_out_cnt, size_t cand_stride, size_t out_stride, int n_lists, int n_sup,
-                       char *d_work, int *h_flag, bool *sorted, int *d_redo = nullptr) {
+                       char *d_work, int *h_flag, bool *sorted, int *d_redo = nullptr, int max_total = 0x7fffffff) {
     SortPlan *d_plans = (SortPlan *)d_work;
     int *d_own = (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_own + 64;
     int *d_flag = d_redo ? d_redo : d_own;
@@ -1763,10 +1767,10 @@ static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const i
     const dim3 slices((unsigned)((n_sup + PLAN_SLICE - 1) / PLAN_SLICE), (unsigned)n_lists);
     hipLaunchKernelGGL(corner_sort_hist, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_hist);
     hipLaunchKernelGGL(corner_sort_plan, dim3((unsigned)n_lists), dim3(1024), 0, ctx->stream, (const int *)d_hist, d_max, quality,
-                       d_plans, d_out_cnt, d_flag);
+                       d_plans, d_out_cnt, d_flag, max_total, std::max(4, std::min(PLAN_BUCKETS, 256 / n_lists)));
     hipLaunchKernelGGL(corner_sort_scatter, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_plans,
                        d_out, out_stride);
-    const unsigned nb = (unsigned)std::min(SORT_MAXB, n_sup / PLAN_T + 1);
+    const unsigned nb = (unsigned)std::min(SORT_MAXB, std::min(n_sup, max_total) / PLAN_T_MIN + 1);
     hipLaunchKernelGGL(corner_sort_frames<true>, dim3((unsigned)n_lists, nb), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
                        d_cand, d_cnt, d_max, quality, d_out, d_out_cnt, cand_stride, out_stride, d_flag, (const SortPlan *)d_plans);
     KTLVO_HIP(ctx, hipGetLastError());
@@ -1810,6 +1814,8 @@ constexpr int LF_MAX_ROUNDS = 32;
 constexpr int LF_FRAMES_MAX = 48;
 constexpr int LF_FRAMES_QUEUED_MAX = 16; // the same for frames whose grid fits LDS (a faster sequential pass): measured on 1241 x 376 frames
 constexpr int LF_QUEUED = 2;             // launches of the relaxation queued without looking at the flags
+constexpr int FEW_KEYS_MAX = 2 * SORT_CAP; // keys above the threshold per frame that the routes queued on bounds make room for
+constexpr int FEW_FRAMES_SORT_MAX = 8;     // frames per call up to which the sort by ranges beats a workgroup per frame (1241 x 376: 4 frames 0.27 against 0.31 ms, 16 frames 0.52 against 0.48)
 static size_t lf_cells_stride(size_t cells) { return (cells + 1 + 3) & ~(size_t)3; }
 static bool rounds_possible(size_t cells) { return (lf_cells_stride(cells) + LF_SCAN - 1) / LF_SCAN <= (size_t)LF_SCAN_BLOCKS; }
 static size_t rounds_work_bytes(size_t np2, size_t cells, int n_frames) {
@@ -1940,9 +1946,9 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
 static bool lds_sort_likely(size_t area) { return area <= ((size_t)512 << 10); }
 
 // The same for a list of large ROIs without a word from the device in between: every ROI's keys are filtered and sorted
-// in LDS by one workgroup (corner_sort_frames), then its greedy pass runs; the ROIs take turns on one work area, in
-// stream order.  *d_many_out is a device flag that is raised when some ROI had more keys above its threshold than the
-// LDS sort holds, or candidates the queued launches of the relaxation left undecided; the caller looks at it once
+// in LDS by response ranges (bucket_sort with bounds for counts), then its greedy pass runs; the ROIs take turns on one
+// work area, in stream order.  *d_many_out is a device flag that is raised when some ROI had more than FEW_KEYS_MAX keys
+// above its threshold or a plan turned down, or candidates the queued launches of the relaxation left undecided; the caller looks at it once
 // everything has run and then takes select_large for the whole list.
 static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const ktlvo_gftt_params *p, const CornerScratch &s,
                             float *d_xy, float *d_resp, int *d_counts, int cap, int **d_many_out) {
@@ -1954,16 +1960,15 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         const int gw = (rois[r].w + cell - 1) / cell, gh = (rois[r].h + cell - 1) / cell;
         if (!grid_fits_lds(cell, gw, gh)) cells_max = std::max(cells_max, (size_t)gw * gh);
     }
-    const size_t o_n = up((size_t)SORT_CAP * 8), o_flag = o_n + 256, o_cc = o_flag + 256, o_cp = o_cc + up(cells_max * 4);
+    const size_t o_n = up((size_t)FEW_KEYS_MAX * 8), o_flag = o_n + 256, o_cc = o_flag + 256, o_cp = o_cc + up(cells_max * 4);
     const size_t o_rounds = o_cp + up(cells_max * 16);
     size_t rounds_bytes = 0; // the greedy pass as a relaxation, two launches queued blind, where the grid allows it
     for (int r = 0; r < n_roi && dist && ctx->greedy_rounds; r++) {
         const size_t cells = (size_t)((rois[r].w + cell - 1) / cell) * ((rois[r].h + cell - 1) / cell);
-        if (rounds_possible(cells)) rounds_bytes = std::max(rounds_bytes, rounds_work_bytes(SORT_CAP, cells, 1));
+        if (rounds_possible(cells)) rounds_bytes = std::max(rounds_bytes, rounds_work_bytes(FEW_KEYS_MAX, cells, 1));
     }
-    int rc = ensure_aux(ctx, o_rounds + rounds_bytes);
-    if (rc != KTLVO_OK) return rc;
-    rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
+    const size_t o_bucket = o_rounds + rounds_bytes;
+    int rc = ensure_aux(ctx, o_bucket + bucket_work_bytes(1));
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)b;
@@ -1973,9 +1978,11 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
     const int limit = p->max_corners > 0 ? std::min(p->max_corners, cap) : cap;
     for (int r = 0; r < n_roi; r++) {
         const RoiDev &R = rois[r];
-        hipLaunchKernelGGL(corner_sort_frames<false>, dim3(1), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand + R.off,
-                           s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, (size_t)0, (size_t)0, d_many, (const SortPlan *)nullptr);
-        KTLVO_HIP(ctx, hipGetLastError());
+        // one ROI at a time leaves the chip idle: its keys are sorted by response ranges, short sorts side by side
+        bool sorted;
+        rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, 0, 0, 1, R.w * R.h, b + o_bucket,
+                         nullptr, &sorted, d_many, FEW_KEYS_MAX);
+        if (rc != KTLVO_OK) return rc;
         float *xy = d_xy + (size_t)r * cap * 2, *resp = d_resp + (size_t)r * cap;
         if (!dist) {
             hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256), dim3(256), 0, ctx->stream, d_keys, d_n, R.w, limit, xy,
@@ -1993,7 +2000,7 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
             LfArgs l;
             l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = a.gw; l.gh = a.gh; l.min_dist = p->min_dist; l.limit = limit;
             l.xy = xy; l.resp = resp; l.count = d_counts + r; l.out_stride = 0; l.n_frames = 1;
-            rc = run_rounds(ctx, l, SORT_CAP, SORT_CAP, b + o_rounds, nullptr, LF_QUEUED, d_many);
+            rc = run_rounds(ctx, l, FEW_KEYS_MAX, FEW_KEYS_MAX, b + o_rounds, nullptr, LF_QUEUED, d_many);
             if (rc != KTLVO_OK) return rc;
             continue;
         }
@@ -2051,13 +2058,18 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         // Every frame filtered and sorted by one workgroup in LDS, then the greedy pass: nothing is sized on the host, so
         // the whole detection is queued in one go and the host waits once, at the end, to learn whether a frame had more
         // keys than the LDS sort holds; then, and only then, the global path below does the batch again.
-        const size_t o_n = up((size_t)SORT_CAP * 8 * n_frames), o_flag = o_n + up(4 * (size_t)n_frames), o_cc = o_flag + 256;
+        // few frames leave the chip idle: their keys are sorted by response ranges (short sorts side by side) and the
+        // greedy pass is the relaxation; many frames get a workgroup each for the sort and for the walk
+        const bool few = n_frames <= FEW_FRAMES_SORT_MAX;
+        const size_t kstride = few ? (size_t)FEW_KEYS_MAX : (size_t)SORT_CAP;
+        const size_t o_n = up(kstride * 8 * n_frames), o_flag = o_n + up(4 * (size_t)n_frames), o_cc = o_flag + 256;
         const size_t o_cp = o_cc + (global_grid ? up(cells * 4 * n_frames) : 0);
         const size_t o_rounds = o_cp + (global_grid ? up(cells * 16 * n_frames) : 0);
         // few frames: the greedy pass as a relaxation, two launches queued blind (a frame they do not settle raises
         // the same flag as one with too many keys)
         const bool rounds = dist && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_QUEUED_MAX;
-        const size_t total = o_rounds + (rounds ? rounds_work_bytes(SORT_CAP, cells, n_frames) : 0);
+        const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(kstride, cells, n_frames) : 0);
+        const size_t total = o_bucket + (few ? bucket_work_bytes(n_frames) : 0);
         rc = ensure_aux(ctx, total);
         if (rc != KTLVO_OK) return rc;
         rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
@@ -2067,21 +2079,28 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         int *d_n = (int *)(b + o_n), *d_many = (int *)(b + o_flag);
         KTLVO_HIP(ctx, hipMemsetAsync(b + o_flag, 0, o_cp - o_flag, ctx->stream)); // the flag and, if used, the cells' counts
         if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
-        hipLaunchKernelGGL(corner_sort_frames<false>, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream, s.d_cand,
-                           s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, (size_t)SORT_CAP, d_many, (const SortPlan *)nullptr);
-        KTLVO_HIP(ctx, hipGetLastError());
+        if (few) {
+            bool sorted;
+            rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, kstride, n_frames, (int)area, b + o_bucket,
+                             nullptr, &sorted, d_many, FEW_KEYS_MAX);
+            if (rc != KTLVO_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(corner_sort_frames<false>, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
+                               s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, kstride, d_many, (const SortPlan *)nullptr);
+            KTLVO_HIP(ctx, hipGetLastError());
+        }
         if (!dist) {
             hipLaunchKernelGGL(corner_take_first, dim3((limit + 255) / 256, (unsigned)n_frames), dim3(256), 0, ctx->stream, d_keys,
-                               d_n, roi.w, limit, d_xy, d_resp, d_counts, (size_t)SORT_CAP, (size_t)cap);
+                               d_n, roi.w, limit, d_xy, d_resp, d_counts, kstride, (size_t)cap);
             KTLVO_HIP(ctx, hipGetLastError());
         } else {
-            a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = (size_t)SORT_CAP;
+            a.keys = d_keys; a.n_ptr = d_n; a.keys_stride = kstride;
             a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp);
             if (rounds) {
                 LfArgs l;
                 l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
                 l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
-                rc = run_rounds(ctx, l, SORT_CAP, SORT_CAP, b + o_rounds, nullptr, LF_QUEUED, d_many);
+                rc = run_rounds(ctx, l, (int)kstride, kstride, b + o_rounds, nullptr, LF_QUEUED, d_many);
             } else {
                 rc = launch_select_large(ctx, a, n_frames);
             }
