@@ -909,7 +909,11 @@ __global__ __launch_bounds__(1024) void corner_sort_plan(const int *g_hist, cons
     SortPlan &P = plans[f];
     if (tid <= SORT_MAXB) {
         int fb = PLAN_BINS; // buckets no bin starts in are empty: they begin where the next one does
-        for (int b = tid; b <= SORT_MAXB; b++) fb = min(fb, s_first[b]);
+#pragma unroll
+        for (int b = 0; b <= SORT_MAXB; b++) { // (every lane reads every entry: broadcasts, all in flight together)
+            const int v = s_first[b];
+            fb = b >= tid ? min(fb, v) : fb;
+        }
         P.first_bin[tid] = fb;
         P.off[tid] = fb == PLAN_BINS ? total : pre[fb];
         P.cursor[tid] = 0;
