@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
             if (w > wv) break; // only stronger candidates count: those of this wave's 64 and the waves' before
             unsigned long long m = 0ull;
             const int jend = n < (w + 1) * 64 ? n : (w + 1) * 64;
-            for (int j = w * 64; j < jend; j++) { // the same j in every lane: LDS broadcasts
+#pragma unroll 8
+            for (int j = w * 64; j < jend; j++) { // the same j in every lane: LDS broadcasts, several in flight
                 const unsigned q = (unsigned)keys[j], qc = cxy[j];
                 const int ddx = xc - (int)(qc & 0xffffu), ddy = yc - (int)(qc >> 16);
                 const float dx = (float)x - (float)(q & 0xffffu), dy = (float)y - (float)(q >> 16);
