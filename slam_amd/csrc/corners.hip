@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
         // within reach (in the nine cells around its own, as the walk's grid look-up) as a 256-bit mask in registers,
         // and rounds over two 256-bit masks in LDS (accepted, rejected; a wave writes its 64 bits by ballot) settle
         // everyone, one barrier per round; the accepted leave in rank order, the first `limit` of them.
-        __shared__ unsigned cxy[256];
+        __shared__ uint2 info[256]; // x | y << 16, cell x | cell y << 16
         __shared__ unsigned long long s_acc[4], s_rej[4];
         const int lane = tid & 63, wv = tid >> 6;
         const bool have = tid < n;
@@ -515,26 +515,41 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
         if (have) {
             const unsigned idx = (unsigned)keys[tid];
             x = idx & 0xffffu; y = idx >> 16; xc = x / cell; yc = y / cell;
-            cxy[tid] = (unsigned)xc | ((unsigned)yc << 16);
+            info[tid] = uint2{idx, (unsigned)xc | ((unsigned)yc << 16)};
         }
         if (tid < 4) { s_acc[tid] = 0ull; s_rej[tid] = 0ull; }
         __syncthreads();
-        unsigned long long pred[4] = {0ull, 0ull, 0ull, 0ull};
+        // Squared distances as integers: a region has at most 4096 pixels, so dx^2 + dy^2 stays below 2^24, where the
+        // walk's float arithmetic is exact as well, and an integer is below md^2 exactly when it is below its ceiling.
+        const int md2i = md2 >= 1073741824.0 ? 0x7fffffff : (int)ceil(md2);
+        // Key j's data is the same in every lane (one LDS address: a broadcast), so it goes through readfirstlane and
+        // is unpacked by the scalar unit; the mask grows 32 keys a word, the bit a scalar too.
+        unsigned pw[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w > wv) break; // only stronger candidates count: those of this wave's 64 and the waves' before
-            unsigned long long m = 0ull;
-            const int jend = n < (w + 1) * 64 ? n : (w + 1) * 64;
-#pragma unroll 8
-            for (int j = w * 64; j < jend; j++) { // the same j in every lane: LDS broadcasts, several in flight
-                const unsigned q = (unsigned)keys[j], qc = cxy[j];
-                const int ddx = xc - (int)(qc & 0xffffu), ddy = yc - (int)(qc >> 16);
-                const float dx = (float)x - (float)(q & 0xffffu), dy = (float)y - (float)(q >> 16);
-                const bool c = j < tid && ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && (double)(dx * dx + dy * dy) < md2;
-                m |= (unsigned long long)c << (j & 63);
+        for (int w = 0; w < 8; w++) {
+            if (w * 32 > wv * 64 + 63) break; // only stronger candidates count: none of these 32 ranks before this wave's
+            unsigned m = 0u;
+            for (int j0 = w * 32; j0 < (w + 1) * 32 && j0 < n; j0 += 8) { // eight keys' data fetched together, then used
+                uint2 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) q[u] = info[j0 + u]; // (beyond n: whatever LDS holds, masked out below)
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const unsigned q0 = __builtin_amdgcn_readfirstlane(q[u].x), q1 = __builtin_amdgcn_readfirstlane(q[u].y);
+                    const int dx = x - (int)(q0 & 0xffffu), dy = y - (int)(q0 >> 16);
+                    const unsigned ax = (unsigned)(xc + 1 - (int)(q1 & 0xffffu)), ay = (unsigned)(yc + 1 - (int)(q1 >> 16));
+                    // in the nine cells around, and within reach
+                    const bool c = j0 + u < n && ax <= 2u && ay <= 2u && dx * dx + dy * dy < md2i;
+                    m |= c ? 1u << ((j0 + u) & 31) : 0u;
+                }
             }
-            pred[w] = m;
+            // of these 32 only the ranks below this thread's
+            const int below = tid - w * 32;
+            pw[w] = m & (below >= 32 ? 0xffffffffu : below <= 0 ? 0u : (1u << below) - 1u);
         }
+        unsigned long long pred[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) pred[w] = (unsigned long long)pw[2 * w] | ((unsigned long long)pw[2 * w + 1] << 32);
         int st = have ? 0 : 2; // 0 undecided, 1 accepted, 2 rejected (or no candidate)
         for (int round = 0; round < 257; round++) { // the strongest undecided candidate decides in every round
             if (st == 0) {
