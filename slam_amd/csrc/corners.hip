@@ -293,8 +293,12 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
                                                               unsigned long long *cand, int *cand_cnt, CwGrid g, int n_roi,
                                                               const int *roi_slots) {
     __shared__ unsigned long long buf_all[4][CW_BUF + 64];
+    __shared__ int wg_n[4], wg_roi[4], wg_base[4]; // the waves' last flush: keys held, ROI, places reserved by the ROI's first wave
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long *const buf = buf_all[wave];
+    // (a wave that leaves without work takes no part in the last flush; a barrier does not wait for waves that have ended)
+    if (lane == 0) { wg_n[wave] = 0; wg_roi[wave] = -1; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // wave tasks are dealt like corner_candidates' tiles: the workgroups of one XCD walk a contiguous run of tasks
     const int per_roi = g.strips * g.bands, n_tasks = per_roi * n_roi;
     const int n_groups = (n_tasks + 3) >> 2, per_xcd = (n_groups + 7) >> 3;
@@ -414,9 +418,32 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
         if (i + 2 >= n_iter) break;
         step(i + 2, d0, d1, d2, q0, q2, s0, sb1, sb2, m0, m1, m2, v1, v2);
     }
-    flush();
+    // The last flush -- for most waves the only one -- reserves the places of all waves of the workgroup that work on the
+    // same ROI with ONE atomic: returning atomics on a single address queue up at one L2 channel at about 10 ns each, and
+    // a 3840 x 2160 frame on its own has 3000 waves.
+    if (lane == 0) { wg_n[wave] = n_buf; wg_roi[wave] = roi_id; }
+    __syncthreads();
+    {
+        int before = 0, total = 0, first = wave;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (wg_roi[w] != roi_id) continue;
+            const int c = wg_n[w];
+            if (w < wave) { before += c; first = min(first, w); }
+            total += c;
+        }
+        if (wave == first && lane == 0) wg_base[wave] = total ? atomicAdd(&cand_cnt[roi_id], total) : 0;
+        __syncthreads();
+        const int base = wg_base[first] + before;
+        for (int i = lane; i < n_buf; i += 64) cand[R.off + base + i] = buf[i];
+    }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0 && vmax > -INFINITY) atomicMax(&roi_max[roi_id], f2ord(vmax));
+    // Thousands of atomics on one ROI's maximum queue up at one L2 channel (10 ns each: as long as the rest of a 4K
+    // frame's launch); the maximum only grows, so a wave whose own is not above what is already there has nothing to add.
+    if (lane == 0 && vmax > -INFINITY) {
+        const unsigned o = f2ord(vmax);
+        if (o > __hip_atomic_load(&roi_max[roi_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&roi_max[roi_id], o);
+    }
 }
 
 struct SelArgs {
@@ -1685,7 +1712,13 @@ static int run_candidates(ktlvo_ctx *ctx, int slot, int n_roi, int maxw, int max
     if (large && ctx->candidates_wave && minw >= 8 && minh >= 8) {
         CwGrid g;
         g.strips = (maxw + CW_COLS - 1) / CW_COLS;
+        // Bands of about 48 rows keep the rows a band computes beyond its own (five) at a tenth.  A launch that way too
+        // small to give every SIMD a few waves (one frame, a few) takes lower bands, down to 12 rows: a wave's time is
+        // its rows one after the other, and more, shorter waves finish sooner where the chip is idle anyway.
         g.bands = std::max(1, (maxh + 24) / 48);
+        const long per_band = (long)g.strips * n_roi;
+        if (per_band * g.bands < 2048 && ctx->candidates_low_bands)
+            g.bands = std::max(g.bands, (int)std::min<long>(std::max(1, maxh / 12), (2048 + per_band - 1) / per_band));
         g.band_rows = (maxh + g.bands - 1) / g.bands;
         const int groups = (g.strips * g.bands * n_roi + 3) / 4;
         const dim3 grid(8 * ((groups + 7) / 8));
