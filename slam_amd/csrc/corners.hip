@@ -861,16 +861,17 @@ __device__ __forceinline__ void sort_stage(u64 *sk, int t, int np2, u64 (&k)[16]
 // Frames with more keys than one workgroup sorts: the keys above the threshold are split by response into stretches
 // ("buckets") of at most SORT_CAP keys, each sorted by a workgroup of its own behind the stronger ones.  Four launches:
 // corner_sort_hist counts the keys in PLAN_BINS bins of equal width in the responses' ordered integer form, strongest
-// first (a workgroup per PLAN_SLICE candidates: histogram in LDS, then added to the frame's in global memory);
+// first (a workgroup per slice of 16384 or 4096 candidates: histogram in LDS, then added to the frame's in global memory);
 // corner_sort_plan (a workgroup per frame) cuts the row of bins wherever the running count passes a multiple of T, the
 // frame's bucket size -- a bucket then holds fewer than T keys plus one bin's, which is why a bin with more than
 // SORT_CAP - T keys (thousands of equal responses) sends the call to the global sort.  T is the frame's key count over
 // the number of buckets wanted (PLAN_BUCKETS for a frame on its own: short sorts side by side where most of the chip
 // is idle anyway; a compute unit's worth per frame for a batch), within PLAN_T_MIN ... PLAN_T_MAX, and never more than
 // SORT_MAXB buckets;
-// corner_sort_scatter moves every key into its bucket's stretch of the output (a workgroup per PLAN_SLICE candidates
+// corner_sort_scatter moves every key into its bucket's stretch of the output (a workgroup per slice of candidates
 // claims a run of places per bucket); corner_sort_frames<true> sorts each stretch where it lies.
-constexpr int PLAN_BINS = 8192, SORT_MAXB = 63, PLAN_SLICE = 16384;
+constexpr int PLAN_BINS = 8192, SORT_MAXB = 63;
+constexpr int PLAN_SLICE_BIG = 16384, PLAN_SLICE_SMALL = 4096; // candidates per workgroup of the histogram and the scatter; the small one where few workgroups would result
 constexpr int PLAN_BUCKETS = 48, PLAN_T_MIN = 1792, PLAN_T_MAX = 7680;
 struct SortPlan {
     unsigned max_ord;
@@ -889,6 +890,7 @@ __device__ __forceinline__ int plan_shift(unsigned omax, float thr) {
 __device__ __forceinline__ unsigned plan_bin(unsigned omax, int shift, u64 key) {
     return min((omax - (unsigned)(key >> 32)) >> shift, (unsigned)PLAN_BINS - 1);
 }
+template <int PLAN_SLICE>
 __global__ __launch_bounds__(1024) void corner_sort_hist(const unsigned long long *cand, const int *cand_cnt,
                                                          const unsigned *roi_max, double quality, size_t cand_stride, int *g_hist) {
     __shared__ int hist[PLAN_BINS];
@@ -967,6 +969,7 @@ __global__ __launch_bounds__(1024) void corner_sort_plan(const int *g_hist, cons
         if (bad) *too_many = 1;
     }
 }
+template <int PLAN_SLICE>
 __global__ __launch_bounds__(1024) void corner_sort_scatter(const unsigned long long *cand, const int *cand_cnt,
                                                             const unsigned *roi_max, double quality, size_t cand_stride,
                                                             SortPlan *plans, unsigned long long *out, size_t out_stride) {
@@ -1817,12 +1820,24 @@ static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const i
     int rc = allow_big_lds(ctx, corner_sort_frames<true>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort_buckets);
     if (rc != KTLVO_OK) return rc;
     KTLVO_HIP(ctx, hipMemsetAsync(d_own, 0, 256 + (size_t)n_lists * PLAN_BINS * 4, ctx->stream)); // flag and histograms
-    const dim3 slices((unsigned)((n_sup + PLAN_SLICE - 1) / PLAN_SLICE), (unsigned)n_lists);
-    hipLaunchKernelGGL(corner_sort_hist, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_hist);
+    // (small slices where big ones would give fewer workgroups than the chip has compute units)
+    const bool small = ((size_t)n_sup + PLAN_SLICE_BIG - 1) / PLAN_SLICE_BIG * (size_t)n_lists < 256;
+    const int slice = small ? PLAN_SLICE_SMALL : PLAN_SLICE_BIG;
+    const dim3 slices((unsigned)((n_sup + slice - 1) / slice), (unsigned)n_lists);
+    if (small)
+        hipLaunchKernelGGL(corner_sort_hist<PLAN_SLICE_SMALL>, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality,
+                           cand_stride, d_hist);
+    else
+        hipLaunchKernelGGL(corner_sort_hist<PLAN_SLICE_BIG>, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality,
+                           cand_stride, d_hist);
     hipLaunchKernelGGL(corner_sort_plan, dim3((unsigned)n_lists), dim3(1024), 0, ctx->stream, (const int *)d_hist, d_max, quality,
                        d_plans, d_out_cnt, d_flag, max_total, std::max(4, std::min(PLAN_BUCKETS, 256 / n_lists)));
-    hipLaunchKernelGGL(corner_sort_scatter, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality, cand_stride, d_plans,
-                       d_out, out_stride);
+    if (small)
+        hipLaunchKernelGGL(corner_sort_scatter<PLAN_SLICE_SMALL>, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality,
+                           cand_stride, d_plans, d_out, out_stride);
+    else
+        hipLaunchKernelGGL(corner_sort_scatter<PLAN_SLICE_BIG>, slices, dim3(1024), 0, ctx->stream, d_cand, d_cnt, d_max, quality,
+                           cand_stride, d_plans, d_out, out_stride);
     const unsigned nb = (unsigned)std::min(SORT_MAXB, std::min(n_sup, max_total) / PLAN_T_MIN + 1);
     hipLaunchKernelGGL(corner_sort_frames<true>, dim3((unsigned)n_lists, nb), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
                        d_cand, d_cnt, d_max, quality, d_out, d_out_cnt, cand_stride, out_stride, d_flag, (const SortPlan *)d_plans);
