@@ -1491,6 +1491,23 @@ __global__ __launch_bounds__(1024) void lf_scan_blocks(LfArgs a) {
     const int e = wg_scan_1024(v, s_wave, &total);
     if ((int)threadIdx.x < a.scan_blocks) b[threadIdx.x] = e;
 }
+// The same in one launch for grids of a few stretches: a workgroup per frame takes them one after the other.
+__global__ __launch_bounds__(1024) void lf_scan_few(LfArgs a) {
+    __shared__ int s_wave[16];
+    const int f = blockIdx.x;
+    int run = 0;
+    for (int b = 0; b < a.scan_blocks; b++) {
+        const size_t off = (size_t)b * LF_SCAN + threadIdx.x * 4;
+        const bool in = off < a.cells_stride;
+        const size_t c = f * a.cells_stride + off;
+        const int4 v = in ? *(const int4 *)(a.cell_cnt + c) : int4{0, 0, 0, 0};
+        int total;
+        const int e = wg_scan_1024(v.x + v.y + v.z + v.w, s_wave, &total);
+        if (in) *(int4 *)(a.start + c) = int4{e, e + v.x, e + v.x + v.y, e + v.x + v.y + v.z};
+        if (threadIdx.x == 0) a.blk_off[f * LF_SCAN_BLOCKS + b] = run;
+        run += total;
+    }
+}
 __device__ __forceinline__ int lf_first(const int *start, const int *blk_off, int c) { return start[c] + blk_off[c / LF_SCAN]; }
 __global__ __launch_bounds__(256) void lf_fill(LfArgs a) {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -1810,16 +1827,19 @@ static int allow_big_lds(ktlvo_ctx *ctx, K kernel, size_t bytes, bool &done) {
 // list empty, so whatever is queued behind does nothing with it), and the caller finds out when it next waits; n_sup
 // may then be a bound (the ROI's area) and max_total says how many keys above the threshold out[] has room for.
 static size_t bucket_plans_bytes(int n_lists) { return (sizeof(SortPlan) * (size_t)n_lists + 255) & ~(size_t)255; }
-static size_t bucket_work_bytes(int n_lists) { return bucket_plans_bytes(n_lists) + 256 + (size_t)n_lists * PLAN_BINS * 4; }
+static size_t bucket_zero_bytes(int n_lists) { return 256 + (size_t)n_lists * PLAN_BINS * 4; }
+static size_t bucket_work_bytes(int n_lists) { return bucket_plans_bytes(n_lists) + bucket_zero_bytes(n_lists); }
 static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const int *d_cnt, const unsigned *d_max, double quality,
                        unsigned long long *d_out, int *d_out_cnt, size_t cand_stride, size_t out_stride, int n_lists, int n_sup,
-                       char *d_work, int *h_flag, bool *sorted, int *d_redo = nullptr, int max_total = 0x7fffffff) {
+                       char *d_work, int *h_flag, bool *sorted, int *d_redo = nullptr, int max_total = 0x7fffffff,
+                       char *d_zero = nullptr) {
     SortPlan *d_plans = (SortPlan *)d_work;
-    int *d_own = (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_own + 64;
+    // (d_zero: memory of bucket_zero_bytes() the caller has cleared for the flag and the histograms)
+    int *d_own = d_zero ? (int *)d_zero : (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_own + 64;
     int *d_flag = d_redo ? d_redo : d_own;
     int rc = allow_big_lds(ctx, corner_sort_frames<true>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort_buckets);
     if (rc != KTLVO_OK) return rc;
-    KTLVO_HIP(ctx, hipMemsetAsync(d_own, 0, 256 + (size_t)n_lists * PLAN_BINS * 4, ctx->stream)); // flag and histograms
+    if (!d_zero) KTLVO_HIP(ctx, hipMemsetAsync(d_own, 0, bucket_zero_bytes(n_lists), ctx->stream)); // flag and histograms
     // (small slices where big ones would give fewer workgroups than the chip has compute units)
     const bool small = ((size_t)n_sup + PLAN_SLICE_BIG - 1) / PLAN_SLICE_BIG * (size_t)n_lists < 256;
     const int slice = small ? PLAN_SLICE_SMALL : PLAN_SLICE_BIG;
@@ -1876,6 +1896,7 @@ static int launch_select_large(ktlvo_ctx *ctx, const SelLargeArgs &a, int n_rois
 // host has fetched); the last of them raises *d_unsettled if it leaves a candidate undecided, which the caller reads
 // when it next waits for the stream, and then does the frames again another way.
 constexpr int LF_MAX_ROUNDS = 32;
+constexpr int LF_SCAN_FEW = 4; // stretches of LF_SCAN cells up to which one workgroup per frame scans them all (one launch instead of two)
 // The sequential pass takes a workgroup per frame and as long for 200 frames as for one; the relaxation uses the whole
 // chip and takes as long as its frames add up to.  Measured on 1920 x 1080 and 3840 x 2160 frames the two meet at
 // about 50 frames per call.
@@ -1892,8 +1913,13 @@ static size_t rounds_work_bytes(size_t np2, size_t cells, int n_frames) {
     return up(np2 * F) + up(np2 * 8 * F) + 2 * up(cs * 4 * F) + up(cs * 4 * F) + up((size_t)LF_SCAN_BLOCKS * 4 * F) +
            up((np2 / 1024 + 1) * 4 * F) + up((size_t)LF_MAX_ROUNDS * F * 4);
 }
+// (d_cells_zero: memory of rounds_zero_bytes() the caller has cleared -- together with other things, in one go -- for
+// the cells' counts and handed-out places; without it they lie in `work` and are cleared here)
+static size_t rounds_zero_bytes(size_t cells, int n_frames) {
+    return 2 * ((lf_cells_stride(cells) * 4 * (size_t)n_frames + 255) & ~(size_t)255);
+}
 static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *work, int *h_flags, int queued = 0,
-                      int *d_unsettled = nullptr) {
+                      int *d_unsettled = nullptr, char *d_cells_zero = nullptr) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t F = (size_t)a.n_frames, cs = lf_cells_stride((size_t)a.gw * a.gh);
     a.keys_stride = np2; a.cells_stride = cs; a.blk_stride = np2 / 1024 + 1;
@@ -1907,13 +1933,21 @@ static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *wor
     a.blk_off = (int *)w; w += up((size_t)LF_SCAN_BLOCKS * 4 * F);
     a.blk_cnt = (int *)w; w += up(a.blk_stride * 4 * F);
     a.flags = (int *)w;
-    KTLVO_HIP(ctx, hipMemsetAsync(a.cell_cnt, 0, 2 * up(cs * 4 * F), ctx->stream)); // counts and handed-out places
+    if (d_cells_zero) {
+        a.cell_cnt = (int *)d_cells_zero; a.cell_fill = (int *)(d_cells_zero + up(cs * 4 * F));
+    } else {
+        KTLVO_HIP(ctx, hipMemsetAsync(a.cell_cnt, 0, 2 * up(cs * 4 * F), ctx->stream)); // counts and handed-out places
+    }
     a.last_round = queued - 1; a.unsettled = queued ? d_unsettled : a.flags;
     if (!queued) KTLVO_HIP(ctx, hipMemsetAsync(a.flags, 0, (size_t)LF_MAX_ROUNDS * F * 4, ctx->stream));
     const dim3 g256((unsigned)((n_sup + 255) / 256), (unsigned)F), g1024((unsigned)((n_sup + 1023) / 1024), (unsigned)F);
     hipLaunchKernelGGL(lf_count, g256, dim3(256), 0, ctx->stream, a);
-    hipLaunchKernelGGL(lf_scan_cells, dim3((unsigned)a.scan_blocks, (unsigned)F), dim3(1024), 0, ctx->stream, a);
-    hipLaunchKernelGGL(lf_scan_blocks, dim3((unsigned)F), dim3(1024), 0, ctx->stream, a);
+    if (a.scan_blocks <= LF_SCAN_FEW) {
+        hipLaunchKernelGGL(lf_scan_few, dim3((unsigned)F), dim3(1024), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(lf_scan_cells, dim3((unsigned)a.scan_blocks, (unsigned)F), dim3(1024), 0, ctx->stream, a);
+        hipLaunchKernelGGL(lf_scan_blocks, dim3((unsigned)F), dim3(1024), 0, ctx->stream, a);
+    }
     hipLaunchKernelGGL(lf_fill, g256, dim3(256), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     bool settled = queued > 0;
@@ -1953,7 +1987,8 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     const size_t o_rounds = o_cp + up((size_t)gw * gh * 16);
     const bool rounds = dist && ctx->greedy_rounds && !grid_fits_lds(cell, gw, gh) && rounds_possible((size_t)gw * gh);
     const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(np2, (size_t)gw * gh, 1) : 0);
-    const size_t total = o_bucket + bucket_work_bytes(1);
+    const size_t o_zero = o_bucket + bucket_work_bytes(1); // for the blind route, cleared in one go: sort flag, histogram, cell counters
+    const size_t total = o_zero + bucket_zero_bytes(1) + (rounds ? rounds_zero_bytes((size_t)gw * gh, 1) : 0);
     int rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
@@ -1962,8 +1997,9 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     const bool global_grid = dist && !grid_fits_lds(cell, gw, gh);
     bool sorted = false;
     if (ctx->frames_lds_sort) { // by response ranges in LDS
+        if (blind) KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
         rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi, p->quality, d_keys, d_n, 0, 0, 1, n_sup, b + o_bucket,
-                         h_flags, &sorted, blind ? s.d_overflow + 1 : nullptr);
+                         h_flags, &sorted, blind ? s.d_overflow + 1 : nullptr, 0x7fffffff, blind ? b + o_zero : nullptr);
         if (rc != KTLVO_OK) return rc;
     }
     if (!sorted) {
@@ -1987,7 +2023,8 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
             LfArgs l;
             l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
             l.xy = d_xy; l.resp = d_resp; l.count = d_count; l.out_stride = 0; l.n_frames = 1;
-            if (blind && sorted) return run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1);
+            if (blind && sorted)
+                return run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1, b + o_zero + bucket_zero_bytes(1));
             rc = run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_flags);
             if (rc != KTLVO_ERR_STATE) return rc;
         }
@@ -2036,7 +2073,13 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         if (rounds_possible(cells)) rounds_bytes = std::max(rounds_bytes, rounds_work_bytes(FEW_KEYS_MAX, cells, 1));
     }
     const size_t o_bucket = o_rounds + rounds_bytes;
-    int rc = ensure_aux(ctx, o_bucket + bucket_work_bytes(1));
+    // what has to start at zero for a ROI (the sort's flag and histogram, the relaxation's cell counters) lies together
+    // and is cleared in one go
+    size_t zero_max = 0;
+    for (int r = 0; r < n_roi && dist && ctx->greedy_rounds; r++)
+        zero_max = std::max(zero_max, rounds_zero_bytes((size_t)((rois[r].w + cell - 1) / cell) * ((rois[r].h + cell - 1) / cell), 1));
+    const size_t o_zero = o_bucket + bucket_work_bytes(1);
+    int rc = ensure_aux(ctx, o_zero + bucket_zero_bytes(1) + zero_max);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
     unsigned long long *d_keys = (unsigned long long *)b;
@@ -2048,8 +2091,11 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         const RoiDev &R = rois[r];
         // one ROI at a time leaves the chip idle: its keys are sorted by response ranges, short sorts side by side
         bool sorted;
+        const size_t cells_r = dist ? (size_t)((R.w + cell - 1) / cell) * ((R.h + cell - 1) / cell) : 0;
+        const bool relax_r = dist && ctx->greedy_rounds && rounds_possible(cells_r);
+        KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, bucket_zero_bytes(1) + (relax_r ? rounds_zero_bytes(cells_r, 1) : 0), ctx->stream));
         rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, 0, 0, 1, R.w * R.h, b + o_bucket,
-                         nullptr, &sorted, d_many, FEW_KEYS_MAX);
+                         nullptr, &sorted, d_many, FEW_KEYS_MAX, b + o_zero);
         if (rc != KTLVO_OK) return rc;
         float *xy = d_xy + (size_t)r * cap * 2, *resp = d_resp + (size_t)r * cap;
         if (!dist) {
@@ -2064,11 +2110,11 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         a.cell_cnt = (int *)(b + o_cc); a.cell_pts = (uint4 *)(b + o_cp); a.limit = limit;
         a.xy = xy; a.resp = resp; a.count = d_counts + r; a.overflow = s.d_overflow;
         a.keys_stride = a.cells_stride = a.out_stride = 0;
-        if (ctx->greedy_rounds && rounds_possible((size_t)a.gw * a.gh)) {
+        if (relax_r) {
             LfArgs l;
             l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = a.gw; l.gh = a.gh; l.min_dist = p->min_dist; l.limit = limit;
             l.xy = xy; l.resp = resp; l.count = d_counts + r; l.out_stride = 0; l.n_frames = 1;
-            rc = run_rounds(ctx, l, FEW_KEYS_MAX, FEW_KEYS_MAX, b + o_rounds, nullptr, LF_QUEUED, d_many);
+            rc = run_rounds(ctx, l, FEW_KEYS_MAX, FEW_KEYS_MAX, b + o_rounds, nullptr, LF_QUEUED, d_many, b + o_zero + bucket_zero_bytes(1));
             if (rc != KTLVO_OK) return rc;
             continue;
         }
@@ -2137,7 +2183,8 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         // the same flag as one with too many keys)
         const bool rounds = dist && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_QUEUED_MAX;
         const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(kstride, cells, n_frames) : 0);
-        const size_t total = o_bucket + (few ? bucket_work_bytes(n_frames) : 0);
+        const size_t o_zero = o_bucket + (few ? bucket_work_bytes(n_frames) : 0); // cleared in one go: sort flag, histograms, cell counters
+        const size_t total = o_zero + (few ? bucket_zero_bytes(n_frames) + (rounds ? rounds_zero_bytes(cells, n_frames) : 0) : 0);
         rc = ensure_aux(ctx, total);
         if (rc != KTLVO_OK) return rc;
         rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
@@ -2149,8 +2196,9 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
         if (few) {
             bool sorted;
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
             rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, kstride, n_frames, (int)area, b + o_bucket,
-                             nullptr, &sorted, d_many, FEW_KEYS_MAX);
+                             nullptr, &sorted, d_many, FEW_KEYS_MAX, b + o_zero);
             if (rc != KTLVO_OK) return rc;
         } else {
             hipLaunchKernelGGL(corner_sort_frames<false>, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
@@ -2168,7 +2216,8 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
                 LfArgs l;
                 l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
                 l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
-                rc = run_rounds(ctx, l, (int)kstride, kstride, b + o_rounds, nullptr, LF_QUEUED, d_many);
+                rc = run_rounds(ctx, l, (int)kstride, kstride, b + o_rounds, nullptr, LF_QUEUED, d_many,
+                                few ? b + o_zero + bucket_zero_bytes(n_frames) : nullptr);
             } else {
                 rc = launch_select_large(ctx, a, n_frames);
             }
@@ -2196,7 +2245,8 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     const size_t o_cp = o_cc + up(cells * 4 * n_frames), o_rounds = o_cp + up(cells * 16 * n_frames);
     const bool rounds = global_grid && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_MAX;
     const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(np2, cells, n_frames) : 0);
-    const size_t total = o_bucket + bucket_work_bytes(n_frames);
+    const size_t o_zero = o_bucket + bucket_work_bytes(n_frames); // for the blind route, cleared in one go
+    const size_t total = o_zero + bucket_zero_bytes(n_frames) + (rounds ? rounds_zero_bytes(cells, n_frames) : 0);
     rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
@@ -2208,8 +2258,9 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         const bool blind = attempt == 0 && ctx->frames_lds_sort && rounds;
         bool sorted = false;
         if (ctx->frames_lds_sort) { // by response ranges in LDS
+            if (blind) KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
             rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, np2, n_frames, n_sup, b + o_bucket, h_many,
-                             &sorted, blind ? s.d_overflow + 1 : nullptr);
+                             &sorted, blind ? s.d_overflow + 1 : nullptr, 0x7fffffff, blind ? b + o_zero : nullptr);
             if (rc != KTLVO_OK) return rc;
         }
         if (!sorted) {
@@ -2231,7 +2282,8 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
                 LfArgs l;
                 l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
                 l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
-                rc = blind ? run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1)
+                rc = blind ? run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1,
+                                        b + o_zero + bucket_zero_bytes(n_frames))
                            : run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_many + 1);
                 if (rc != KTLVO_OK && rc != KTLVO_ERR_STATE) return rc;
             }

@@ -86,9 +86,16 @@ def test_pyramid_scharr_lk_random_sizes(make_ctx, oracle, klib):
                         oracle.set_lk_sum_mode(0)
                     ok = both & (ps_ == 1)
                     d_gpu, d_ord = np.abs(go - oo).max(1)[ok], np.abs(po_ - oo).max(1)[ok]
-                    assert np.quantile(d_gpu, 0.95) <= 1.5 * np.quantile(d_ord, 0.95), (w, h, np.quantile(d_gpu, 0.95),
-                                                                                      np.quantile(d_ord, 0.95))
-                    assert (d_gpu > 0.05).sum() <= 1.5 * (d_ord > 0.05).sum() + 2, (w, h)
+                    # as many points leave the serial oracle's tracks as leave them when the oracle itself sums
+                    # pairwise, and the kernel's tracks lie with one of the oracle's two (95 % within 0.05 px of the
+                    # nearer).  Not the ratio of the two distances' 95th percentiles: where about one point in twenty
+                    # diverges that percentile falls on the edge of the diverging set, among values that jump from
+                    # 0.003 to 0.1 px from one point to the next (seed 777777, 64 x 48: 11 and 10 of 177 points
+                    # diverge, percentiles 0.121 and 0.055 px, while only 2 points are beyond 0.05 px of the
+                    # pairwise oracle's)
+                    assert (d_gpu > 0.05).sum() <= 1.5 * (d_ord > 0.05).sum() + 2, (w, h, (d_gpu > 0.05).sum(), (d_ord > 0.05).sum())
+                    d_near = np.minimum(d_gpu, np.abs(go - po_).max(1)[ok])
+                    assert np.quantile(d_near, 0.95) <= 0.05, (w, h, np.quantile(d_near, 0.95))
                 assert np.all(de <= 0.05 + 200.0 * d), (w, h, float((de - 200.0 * d).max()))
             checked += int(both.sum())
         lost = agree & (gs == 0)
