@@ -296,21 +296,21 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
     __shared__ int wg_n[4], wg_roi[4], wg_base[4]; // the waves' last flush: keys held, ROI, places reserved by the ROI's first wave
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned long long *const buf = buf_all[wave];
-    // (a wave that leaves without work takes no part in the last flush; a barrier does not wait for waves that have ended)
-    if (lane == 0) { wg_n[wave] = 0; wg_roi[wave] = -1; }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // wave tasks are dealt like corner_candidates' tiles: the workgroups of one XCD walk a contiguous run of tasks
     const int per_roi = g.strips * g.bands, n_tasks = per_roi * n_roi;
     const int n_groups = (n_tasks + 3) >> 2, per_xcd = (n_groups + 7) >> 3;
     const int group = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     const int task = group * 4 + wave;
-    if (group >= n_groups || task >= n_tasks) return;
-    const int roi_id = task / per_roi, tr = task - roi_id * per_roi;
+    if (group >= n_groups) return; // (the whole workgroup)
+    // a wave without work -- beyond the last task, or a strip or band beyond a smaller ROI of the list -- stays until the
+    // workgroup's last flush, in which it holds no keys
+    const bool has_task = task < n_tasks;
+    const int roi_id = has_task ? task / per_roi : 0, tr = has_task ? task - roi_id * per_roi : 0;
     const int band = tr / g.strips, strip = tr - band * g.strips;
     const RoiDev R = rois[roi_id];
     const int W = R.w, H = R.h;
     const int x0 = strip * CW_COLS, y0 = band * g.band_rows, y1 = min(y0 + g.band_rows, H);
-    if (x0 >= W || y0 >= H) return;
+    const bool live = has_task && x0 < W && y0 < H;
     const LevelDesc L = slots[roi_slots ? roi_slots[roi_id] : slot].lv[0];
     typedef const __attribute__((address_space(1))) uint8_t *gsrc;
     const int x = x0 - 3 + lane; // ROI-relative column of this lane
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
     // no image row to read: "image row H + 1" stands for it.
     const bool top = y0 == 0;
     const int iy_first = top ? -1 : y0 - 3, iy_last = min(y1 + 2, H + 1);
-    const int n_iter = iy_last - iy_first + 1;
+    const int n_iter = live ? iy_last - iy_first + 1 : 0;
     const int yr_first = top ? 0 : y0 - 1;
 
     float vmax = -INFINITY;
@@ -421,13 +421,13 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
     // The last flush -- for most waves the only one -- reserves the places of all waves of the workgroup that work on the
     // same ROI with ONE atomic: returning atomics on a single address queue up at one L2 channel at about 10 ns each, and
     // a 3840 x 2160 frame on its own has 3000 waves.
-    if (lane == 0) { wg_n[wave] = n_buf; wg_roi[wave] = roi_id; }
+    if (lane == 0) { wg_n[wave] = n_buf; wg_roi[wave] = live ? roi_id : -1; }
     __syncthreads();
     {
         int before = 0, total = 0, first = wave;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            if (wg_roi[w] != roi_id) continue;
+            if (!live || wg_roi[w] != roi_id) continue;
             const int c = wg_n[w];
             if (w < wave) { before += c; first = min(first, w); }
             total += c;
@@ -438,8 +438,8 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
         for (int i = lane; i < n_buf; i += 64) cand[R.off + base + i] = buf[i];
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    // Thousands of atomics on one ROI's maximum queue up at one L2 channel (10 ns each: as long as the rest of a 4K
-    // frame's launch); the maximum only grows, so a wave whose own is not above what is already there has nothing to add.
+    // The maximum only grows, so a wave whose own is not above what is already there has nothing to add (atomics that
+    // return nothing do not queue up the way the reservations above did: leaving these out changed little).
     if (lane == 0 && vmax > -INFINITY) {
         const unsigned o = f2ord(vmax);
         if (o > __hip_atomic_load(&roi_max[roi_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&roi_max[roi_id], o);
