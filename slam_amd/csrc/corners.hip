@@ -938,13 +938,16 @@ __global__ __launch_bounds__(1024) void corner_sort_plan(const int *g_hist, cons
     for (int j = 0; j < 8; j++) { sum += c[j]; mx = max(mx, c[j]); }
     int total;
     int e = wg_scan_1024(sum, s_wave, &total);
-    if (mx > 0) atomicMax(&s_maxbin, mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0 && mx > 0) atomicMax(&s_maxbin, mx);
     int T = (total + buckets_wanted - 1) / buckets_wanted;
     T = T < PLAN_T_MIN ? PLAN_T_MIN : T > PLAN_T_MAX ? PLAN_T_MAX : T;
     // A bin's bucket is the running count before it over T; the first bin of a bucket is the lowest that has it.  Bucket
     // numbers do not fall from bin to bin, so a bin whose bucket is that of a non-empty bin before it -- one of this
     // thread's, or of an earlier lane of the wave (a running maximum over the lanes' last buckets) -- cannot be the
-    // first, and is spared its atomic (thousands of LDS atomics on a handful of addresses: 1.7 of this kernel's 11 us).
+    // first, and is spared its atomic (thousands of LDS atomics on a handful of addresses: 1.7 of this kernel's 11 us;
+    // the largest bin, one atomic per thread on ONE address before it was reduced over the wave first: 2.5 us).
     int bk[8], last = -1;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
