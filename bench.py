@@ -662,7 +662,7 @@ def main():
                                          "value": tracked_full / t_full, "unit": "tracked features/s"},
                   "note": "ktlvo_detect_gftt_frames_dev: Shi-Tomasi corners (quality 0.01, minDistance %g, at most %d) of the "
                           "step's %d first frames in one call, output on the device; one frame per call costs %s" % (
-                              a.min_dist, NF, NP, "0.15 ms at this size" if (W, H) == (1241, 376) else "more")}
+                              a.min_dist, NF, NP, "0.14 ms at this size" if (W, H) == (1241, 376) else "more")}
         del d_cxy, d_cr, d_cc
 
     # ---- the same step fed from host memory every time (frame-pair STREAM, never the headline) ------------
