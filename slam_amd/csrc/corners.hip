@@ -1449,6 +1449,7 @@ struct LfArgs {
     int *blk_cnt;                   // accepted candidates per block of 1024 ranks
     int *flags;                     // [round * n_frames + f]: the launch left a candidate of the frame undecided
     int *unsettled; int last_round; // launch number last_round raises *unsettled as well (launches queued without looking at the flags)
+    int tries;                      // times a candidate looks at its undecided predecessors again within a launch
     int cell, gw, gh, scan_blocks;
     double min_dist;
     int limit;
@@ -1460,7 +1461,6 @@ struct LfArgs {
 constexpr int LF_SCAN = 4096;        // cells per workgroup of the scan
 constexpr int LF_SCAN_BLOCKS = 1024; // at most: grids of up to 4M cells
 constexpr int LF_PEND = 24;          // undecided predecessors a candidate keeps track of within a launch
-constexpr int LF_TRIES = 64;         // times it looks at them again before it leaves the rest to the next launch
 __global__ __launch_bounds__(256) void lf_count(LfArgs a) {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_ptr[f]) return;
@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(256) void lf_fill(LfArgs a) {
 // One launch of the relaxation.  A candidate collects its predecessors within reach from the three rows of cells
 // around it (the three cells of a row are one stretch of the item list; the first four items of every stretch are
 // fetched at once, the rest one by one), reads their states and decides if it can; otherwise it keeps the undecided
-// ones in LDS and looks at them again, up to LF_TRIES times.  Ranks run with the thread index and workgroups start in
+// ones in LDS and looks at them again, up to a.tries times (64 unless the context says otherwise).  Ranks run with the thread index and workgroups start in
 // index order, so a candidate's predecessors belong to workgroups that started no later than its own: most chains
 // settle inside one launch, and what is left (a candidate that ran out of tries, or has more undecided predecessors
 // than it can keep) raises the launch's flag for its frame.
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void lf_round(LfArgs a, int round) {
     // A decision is published the moment it is made, inside the loop: lanes of one wave that wait for each other
     // would otherwise only see it once the whole wave has left the loop.
     bool done = false;
-    for (int t = 0; t <= LF_TRIES && !done; t++) {
+    for (int t = 0; t <= a.tries && !done; t++) {
         if (t) __builtin_amdgcn_s_sleep(2);
         int keep = 0;
         for (int k = 0; k < npend; k += 4) {
@@ -1961,6 +1961,7 @@ static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *wor
         KTLVO_HIP(ctx, hipMemsetAsync(a.cell_cnt, 0, 2 * up(cs * 4 * F), ctx->stream)); // counts and handed-out places
     }
     a.last_round = queued - 1; a.unsettled = queued ? d_unsettled : a.flags;
+    a.tries = ctx->relax_tries;
     if (!queued) KTLVO_HIP(ctx, hipMemsetAsync(a.flags, 0, (size_t)LF_MAX_ROUNDS * F * 4, ctx->stream));
     const dim3 g256((unsigned)((n_sup + 255) / 256), (unsigned)F), g1024((unsigned)((n_sup + 1023) / 1024), (unsigned)F);
     hipLaunchKernelGGL(lf_count, g256, dim3(256), 0, ctx->stream, a);

@@ -493,6 +493,34 @@ def test_sort_by_response_ranges_equals_global_sort(make_ctx, oracle, klib):
         assert np.array_equal(a[-1][0], np.asarray(oxy, np.float32).reshape(-1, 2)) and np.array_equal(a[-1][1], np.asarray(oresp, np.float32))
 
 
+def test_relaxation_that_does_not_settle_is_done_again(make_ctx, oracle, klib):
+    """A context created with KTLVO_RELAX_TRIES=0 never looks at an undecided predecessor twice within a launch, so the
+    two launches queued blind leave most candidates undecided: the flag they raise sends the call through again step by
+    step, where the relaxation gets launches until it settles (or, past 32, the walk takes over).  Frames whose grid
+    fits LDS and frames whose grid does not, per call and three to a call: the corners of an ordinary context and of the
+    oracle."""
+    rng = np.random.default_rng(606)
+    for (W, H), gp in (((640, 360), klib.gftt_params(1500, 0.01, 8.0, 3, 0, 0.0)), ((960, 540), klib.gftt_params(6000, 0.005, 3.0, 3, 0, 0.0))):
+        imgs = [synth.texture_image(W, H, seed=700 + i, periods=(17.0, 8.0, 4.0), noise=True) for i in range(2)]
+        imgs.append(rng.integers(0, 256, (H, W), dtype=np.uint8))
+        plain = make_ctx(width=W, height=H, num_slots=3, max_points=8192)
+        os.environ["KTLVO_RELAX_TRIES"] = "0"
+        try:
+            slow = make_ctx(width=W, height=H, num_slots=3, max_points=8192)
+        finally:
+            del os.environ["KTLVO_RELAX_TRIES"]
+        for ctx in (plain, slow):
+            ctx.upload_images([0, 1, 2], np.stack(imgs))
+        a = plain.detect_gftt_frames([0, 1, 2], gp)
+        b = slow.detect_gftt_frames([0, 1, 2], gp)
+        for f in range(3):
+            assert np.array_equal(a[f][0], b[f][0]) and np.array_equal(a[f][1], b[f][1]), (W, H, f, len(a[f][0]), len(b[f][0]))
+            (xs, rs), = slow.detect_gftt(f, [(0, 0, W, H)], gp)
+            assert np.array_equal(xs, a[f][0]) and np.array_equal(rs, a[f][1]), (W, H, f)
+        oxy, oresp = oracle.good_features(imgs[0], None, gp.max_corners, gp.quality, gp.min_dist, False, 0.0)
+        assert np.array_equal(a[0][0], np.asarray(oxy, np.float32).reshape(-1, 2)) and np.array_equal(a[0][1], np.asarray(oresp, np.float32))
+
+
 def test_sub_region_relaxation_equals_walk(make_ctx, oracle, klib):
     """Sub-regions with up to 256 keys above the threshold take the greedy pass as a relaxation inside their workgroup;
     with more keys, or in a context created with KTLVO_GREEDY_SEQUENTIAL=1, one wave walks the sorted keys.  A grid of the
