@@ -1034,11 +1034,18 @@ __global__ __launch_bounds__(1024) void corner_sort_scatter(const unsigned long 
 }
 
 // BUCKETS: blockIdx.y = the bucket of frame blockIdx.x the workgroup sorts, after plans[]; the frame's count is the plan's.
+// (cells: where the relaxation follows, the keys are counted per minimum-distance cell as they are written out, which
+// spares the relaxation a pass over them; cell == 0: not wanted)
+struct CellCount {
+    int cell, gw;
+    int *cell_cnt;
+    size_t cells_stride;
+};
 template <bool BUCKETS>
 __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long long *cand, const int *cand_cnt,
                                                            const unsigned *roi_max, double quality, unsigned long long *out,
                                                            int *out_cnt, size_t cand_stride, size_t out_stride, int *too_many,
-                                                           const SortPlan *plans) {
+                                                           const SortPlan *plans, CellCount cells) {
     extern __shared__ u64 sk[]; // SORT_LDS_KEYS keys
     __shared__ int s_n;
     cand += blockIdx.x * cand_stride; out += blockIdx.x * out_stride;
@@ -1113,6 +1120,15 @@ __global__ __launch_bounds__(1024) void corner_sort_frames(const unsigned long l
     for (int r = 0; r < 16; r++)
         if (16 * tid + r < m) out[16 * tid + r] = k[r];
     if (!BUCKETS && tid == 0) out_cnt[blockIdx.x] = m;
+    if (BUCKETS && cells.cell) {
+        int *cnt = cells.cell_cnt + blockIdx.x * cells.cells_stride;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (16 * tid + r < m) {
+                const unsigned idx = (unsigned)k[r];
+                atomicAdd(&cnt[(int)((idx >> 16) / (unsigned)cells.cell) * cells.gw + (int)((idx & 0xffffu) / (unsigned)cells.cell)], 1);
+            }
+    }
 }
 
 struct SelLargeArgs {
@@ -1854,7 +1870,7 @@ static size_t bucket_work_bytes(int n_lists) { return bucket_plans_bytes(n_lists
 static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const int *d_cnt, const unsigned *d_max, double quality,
                        unsigned long long *d_out, int *d_out_cnt, size_t cand_stride, size_t out_stride, int n_lists, int n_sup,
                        char *d_work, int *h_flag, bool *sorted, int *d_redo = nullptr, int max_total = 0x7fffffff,
-                       char *d_zero = nullptr) {
+                       char *d_zero = nullptr, CellCount cells = CellCount{0, 0, nullptr, 0}) {
     SortPlan *d_plans = (SortPlan *)d_work;
     // (d_zero: memory of bucket_zero_bytes() the caller has cleared for the flag and the histograms)
     int *d_own = d_zero ? (int *)d_zero : (int *)(d_work + bucket_plans_bytes(n_lists)), *d_hist = d_own + 64;
@@ -1882,7 +1898,7 @@ static int bucket_sort(ktlvo_ctx *ctx, const unsigned long long *d_cand, const i
                            cand_stride, d_plans, d_out, out_stride);
     const unsigned nb = (unsigned)std::min(SORT_MAXB, std::min(n_sup, max_total) / PLAN_T_MIN + 1);
     hipLaunchKernelGGL(corner_sort_frames<true>, dim3((unsigned)n_lists, nb), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
-                       d_cand, d_cnt, d_max, quality, d_out, d_out_cnt, cand_stride, out_stride, d_flag, (const SortPlan *)d_plans);
+                       d_cand, d_cnt, d_max, quality, d_out, d_out_cnt, cand_stride, out_stride, d_flag, (const SortPlan *)d_plans, cells);
     KTLVO_HIP(ctx, hipGetLastError());
     if (d_redo) { // the caller looks at the flag when it next waits for the stream
         *sorted = true;
@@ -1937,11 +1953,16 @@ static size_t rounds_work_bytes(size_t np2, size_t cells, int n_frames) {
 }
 // (d_cells_zero: memory of rounds_zero_bytes() the caller has cleared -- together with other things, in one go -- for
 // the cells' counts and handed-out places; without it they lie in `work` and are cleared here)
-static size_t rounds_zero_bytes(size_t cells, int n_frames) {
-    return 2 * ((lf_cells_stride(cells) * 4 * (size_t)n_frames + 255) & ~(size_t)255);
+// (the cleared memory also holds the candidates' states; with `counted` the cells' counts are already in it -- the sort
+// by ranges wrote them, rounds_cell_count() -- and the counting pass is left out)
+static size_t rounds_zero_bytes(size_t cells, int n_frames, size_t np2) {
+    return 2 * ((lf_cells_stride(cells) * 4 * (size_t)n_frames + 255) & ~(size_t)255) + ((np2 * (size_t)n_frames + 255) & ~(size_t)255);
+}
+static CellCount rounds_cell_count(char *d_cells_zero, int cell, int gw, int gh) {
+    return CellCount{cell, gw, (int *)d_cells_zero, lf_cells_stride((size_t)gw * gh)};
 }
 static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *work, int *h_flags, int queued = 0,
-                      int *d_unsettled = nullptr, char *d_cells_zero = nullptr) {
+                      int *d_unsettled = nullptr, char *d_cells_zero = nullptr, bool counted = false) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t F = (size_t)a.n_frames, cs = lf_cells_stride((size_t)a.gw * a.gh);
     a.keys_stride = np2; a.cells_stride = cs; a.blk_stride = np2 / 1024 + 1;
@@ -1957,6 +1978,7 @@ static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *wor
     a.flags = (int *)w;
     if (d_cells_zero) {
         a.cell_cnt = (int *)d_cells_zero; a.cell_fill = (int *)(d_cells_zero + up(cs * 4 * F));
+        a.state = (unsigned char *)(d_cells_zero + 2 * up(cs * 4 * F));
     } else {
         KTLVO_HIP(ctx, hipMemsetAsync(a.cell_cnt, 0, 2 * up(cs * 4 * F), ctx->stream)); // counts and handed-out places
     }
@@ -1964,7 +1986,7 @@ static int run_rounds(ktlvo_ctx *ctx, LfArgs a, int n_sup, size_t np2, char *wor
     a.tries = ctx->relax_tries;
     if (!queued) KTLVO_HIP(ctx, hipMemsetAsync(a.flags, 0, (size_t)LF_MAX_ROUNDS * F * 4, ctx->stream));
     const dim3 g256((unsigned)((n_sup + 255) / 256), (unsigned)F), g1024((unsigned)((n_sup + 1023) / 1024), (unsigned)F);
-    hipLaunchKernelGGL(lf_count, g256, dim3(256), 0, ctx->stream, a);
+    if (!counted) hipLaunchKernelGGL(lf_count, g256, dim3(256), 0, ctx->stream, a);
     if (a.scan_blocks <= LF_SCAN_FEW) {
         hipLaunchKernelGGL(lf_scan_few, dim3((unsigned)F), dim3(1024), 0, ctx->stream, a);
     } else {
@@ -2011,7 +2033,7 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     const bool rounds = dist && ctx->greedy_rounds && !grid_fits_lds(cell, gw, gh) && rounds_possible((size_t)gw * gh);
     const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(np2, (size_t)gw * gh, 1) : 0);
     const size_t o_zero = o_bucket + bucket_work_bytes(1); // for the blind route, cleared in one go: sort flag, histogram, cell counters
-    const size_t total = o_zero + bucket_zero_bytes(1) + (rounds ? rounds_zero_bytes((size_t)gw * gh, 1) : 0);
+    const size_t total = o_zero + bucket_zero_bytes(1) + (rounds ? rounds_zero_bytes((size_t)gw * gh, 1, np2) : 0);
     int rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
@@ -2022,7 +2044,8 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
     if (ctx->frames_lds_sort) { // by response ranges in LDS
         if (blind) KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
         rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + roi, s.d_max + roi, p->quality, d_keys, d_n, 0, 0, 1, n_sup, b + o_bucket,
-                         h_flags, &sorted, blind ? s.d_overflow + 1 : nullptr, 0x7fffffff, blind ? b + o_zero : nullptr);
+                         h_flags, &sorted, blind ? s.d_overflow + 1 : nullptr, 0x7fffffff, blind ? b + o_zero : nullptr,
+                         blind && rounds ? rounds_cell_count(b + o_zero + bucket_zero_bytes(1), cell, gw, gh) : CellCount{0, 0, nullptr, 0});
         if (rc != KTLVO_OK) return rc;
     }
     if (!sorted) {
@@ -2047,7 +2070,7 @@ static int select_large(ktlvo_ctx *ctx, const RoiDev &R, int roi, int n_sup, con
             l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
             l.xy = d_xy; l.resp = d_resp; l.count = d_count; l.out_stride = 0; l.n_frames = 1;
             if (blind && sorted)
-                return run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1, b + o_zero + bucket_zero_bytes(1));
+                return run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1, b + o_zero + bucket_zero_bytes(1), true);
             rc = run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_flags);
             if (rc != KTLVO_ERR_STATE) return rc;
         }
@@ -2100,7 +2123,7 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
     // and is cleared in one go
     size_t zero_max = 0;
     for (int r = 0; r < n_roi && dist && ctx->greedy_rounds; r++)
-        zero_max = std::max(zero_max, rounds_zero_bytes((size_t)((rois[r].w + cell - 1) / cell) * ((rois[r].h + cell - 1) / cell), 1));
+        zero_max = std::max(zero_max, rounds_zero_bytes((size_t)((rois[r].w + cell - 1) / cell) * ((rois[r].h + cell - 1) / cell), 1, FEW_KEYS_MAX));
     const size_t o_zero = o_bucket + bucket_work_bytes(1);
     int rc = ensure_aux(ctx, o_zero + bucket_zero_bytes(1) + zero_max);
     if (rc != KTLVO_OK) return rc;
@@ -2116,9 +2139,11 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
         bool sorted;
         const size_t cells_r = dist ? (size_t)((R.w + cell - 1) / cell) * ((R.h + cell - 1) / cell) : 0;
         const bool relax_r = dist && ctx->greedy_rounds && rounds_possible(cells_r);
-        KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, bucket_zero_bytes(1) + (relax_r ? rounds_zero_bytes(cells_r, 1) : 0), ctx->stream));
+        KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, bucket_zero_bytes(1) + (relax_r ? rounds_zero_bytes(cells_r, 1, FEW_KEYS_MAX) : 0), ctx->stream));
         rc = bucket_sort(ctx, s.d_cand + R.off, s.d_cnt + r, s.d_max + r, p->quality, d_keys, d_n, 0, 0, 1, R.w * R.h, b + o_bucket,
-                         nullptr, &sorted, d_many, FEW_KEYS_MAX, b + o_zero);
+                         nullptr, &sorted, d_many, FEW_KEYS_MAX, b + o_zero,
+                         relax_r ? rounds_cell_count(b + o_zero + bucket_zero_bytes(1), cell, (R.w + cell - 1) / cell, (R.h + cell - 1) / cell)
+                                 : CellCount{0, 0, nullptr, 0});
         if (rc != KTLVO_OK) return rc;
         float *xy = d_xy + (size_t)r * cap * 2, *resp = d_resp + (size_t)r * cap;
         if (!dist) {
@@ -2137,7 +2162,7 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
             LfArgs l;
             l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = a.gw; l.gh = a.gh; l.min_dist = p->min_dist; l.limit = limit;
             l.xy = xy; l.resp = resp; l.count = d_counts + r; l.out_stride = 0; l.n_frames = 1;
-            rc = run_rounds(ctx, l, FEW_KEYS_MAX, FEW_KEYS_MAX, b + o_rounds, nullptr, LF_QUEUED, d_many, b + o_zero + bucket_zero_bytes(1));
+            rc = run_rounds(ctx, l, FEW_KEYS_MAX, FEW_KEYS_MAX, b + o_rounds, nullptr, LF_QUEUED, d_many, b + o_zero + bucket_zero_bytes(1), true);
             if (rc != KTLVO_OK) return rc;
             continue;
         }
@@ -2207,7 +2232,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         const bool rounds = dist && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_QUEUED_MAX;
         const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(kstride, cells, n_frames) : 0);
         const size_t o_zero = o_bucket + (few ? bucket_work_bytes(n_frames) : 0); // cleared in one go: sort flag, histograms, cell counters
-        const size_t total = o_zero + (few ? bucket_zero_bytes(n_frames) + (rounds ? rounds_zero_bytes(cells, n_frames) : 0) : 0);
+        const size_t total = o_zero + (few ? bucket_zero_bytes(n_frames) + (rounds ? rounds_zero_bytes(cells, n_frames, kstride) : 0) : 0);
         rc = ensure_aux(ctx, total);
         if (rc != KTLVO_OK) return rc;
         rc = allow_big_lds(ctx, corner_sort_frames<false>, (size_t)SORT_LDS_KEYS * 8, ctx->big_lds_sort);
@@ -2221,11 +2246,12 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
             bool sorted;
             KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
             rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, kstride, n_frames, (int)area, b + o_bucket,
-                             nullptr, &sorted, d_many, FEW_KEYS_MAX, b + o_zero);
+                             nullptr, &sorted, d_many, FEW_KEYS_MAX, b + o_zero,
+                             rounds ? rounds_cell_count(b + o_zero + bucket_zero_bytes(n_frames), cell, gw, gh) : CellCount{0, 0, nullptr, 0});
             if (rc != KTLVO_OK) return rc;
         } else {
             hipLaunchKernelGGL(corner_sort_frames<false>, dim3((unsigned)n_frames), dim3(1024), (size_t)SORT_LDS_KEYS * 8, ctx->stream,
-                               s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, kstride, d_many, (const SortPlan *)nullptr);
+                               s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, kstride, d_many, (const SortPlan *)nullptr, CellCount{0, 0, nullptr, 0});
             KTLVO_HIP(ctx, hipGetLastError());
         }
         if (!dist) {
@@ -2240,7 +2266,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
                 l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
                 l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
                 rc = run_rounds(ctx, l, (int)kstride, kstride, b + o_rounds, nullptr, LF_QUEUED, d_many,
-                                few ? b + o_zero + bucket_zero_bytes(n_frames) : nullptr);
+                                few ? b + o_zero + bucket_zero_bytes(n_frames) : nullptr, few);
             } else {
                 rc = launch_select_large(ctx, a, n_frames);
             }
@@ -2269,7 +2295,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     const bool rounds = global_grid && ctx->greedy_rounds && rounds_possible(cells) && n_frames <= LF_FRAMES_MAX;
     const size_t o_bucket = o_rounds + (rounds ? rounds_work_bytes(np2, cells, n_frames) : 0);
     const size_t o_zero = o_bucket + bucket_work_bytes(n_frames); // for the blind route, cleared in one go
-    const size_t total = o_zero + bucket_zero_bytes(n_frames) + (rounds ? rounds_zero_bytes(cells, n_frames) : 0);
+    const size_t total = o_zero + bucket_zero_bytes(n_frames) + (rounds ? rounds_zero_bytes(cells, n_frames, np2) : 0);
     rc = ensure_aux(ctx, total);
     if (rc != KTLVO_OK) return rc;
     char *b = (char *)ctx->d_aux;
@@ -2283,7 +2309,8 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         if (ctx->frames_lds_sort) { // by response ranges in LDS
             if (blind) KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
             rc = bucket_sort(ctx, s.d_cand, s.d_cnt, s.d_max, p->quality, d_keys, d_n, area, np2, n_frames, n_sup, b + o_bucket, h_many,
-                             &sorted, blind ? s.d_overflow + 1 : nullptr, 0x7fffffff, blind ? b + o_zero : nullptr);
+                             &sorted, blind ? s.d_overflow + 1 : nullptr, 0x7fffffff, blind ? b + o_zero : nullptr,
+                             blind ? rounds_cell_count(b + o_zero + bucket_zero_bytes(n_frames), cell, gw, gh) : CellCount{0, 0, nullptr, 0});
             if (rc != KTLVO_OK) return rc;
         }
         if (!sorted) {
@@ -2306,7 +2333,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
                 l.keys = d_keys; l.n_ptr = d_n; l.cell = cell; l.gw = gw; l.gh = gh; l.min_dist = p->min_dist; l.limit = limit;
                 l.xy = d_xy; l.resp = d_resp; l.count = d_counts; l.out_stride = (size_t)cap; l.n_frames = n_frames;
                 rc = blind ? run_rounds(ctx, l, n_sup, np2, b + o_rounds, nullptr, LF_QUEUED, s.d_overflow + 1,
-                                        b + o_zero + bucket_zero_bytes(n_frames))
+                                        b + o_zero + bucket_zero_bytes(n_frames), true)
                            : run_rounds(ctx, l, n_sup, np2, b + o_rounds, h_many + 1);
                 if (rc != KTLVO_OK && rc != KTLVO_ERR_STATE) return rc;
             }
