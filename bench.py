@@ -135,6 +135,9 @@ def parse():
     ap.add_argument("--time-kernels", choices=["lk", "all"], default="lk",
                     help="kernels bracketed by HIP events inside the timed region: the dominant one (default; the "
                          "pyramid kernels are then timed in an untimed pass) or all three")
+    ap.add_argument("--lk-sums", choices=["default", "exact", "tree"], default="default",
+                    help="rounding of LK's window sums (ktlvo_lk_params.sums): the library's default (exact integer "
+                         "totals rounded once), or the float tree")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
     ap.add_argument("--workload", choices=["pairs", "sequence", "ransac", "batch"], default="pairs",
                     help="pairs: the headline frame-pair stream (default); sequence: stereo tracker + pose on a "
@@ -157,6 +160,7 @@ def parse():
     if a.height is None: a.height = shape[1]
     if a.features is None: a.features = shape[2]
     if a.min_dist is None: a.min_dist = shape[3]
+    a.lk_sums = {"default": K.LK_SUMS_DEFAULT, "exact": K.LK_SUMS_EXACT, "tree": K.LK_SUMS_TREE}[a.lk_sums]
     return a
 
 
@@ -338,7 +342,7 @@ def run_batch(a, rank, world, local, dev):
     d_next = torch.zeros_like(d_prev)
     d_status = torch.zeros((max(n_loc, 1), NF), dtype=torch.uint8, device=dev)
     d_err = torch.zeros((max(n_loc, 1), NF), dtype=torch.float32, device=dev)
-    lk = K.lk_params(WIN, a.max_level)
+    lk = K.lk_params(WIN, a.max_level, sums=a.lk_sums)
 
     def step():
         if n_loc:
@@ -555,7 +559,7 @@ def main():
     outs = [(torch.zeros_like(d_prev), torch.zeros((NP, NF), dtype=torch.uint8, device=dev),
              torch.zeros((NP, NF), dtype=torch.float32, device=dev)) for _ in ctxs]
     d_next, d_status, d_err = outs[0]
-    lk = K.lk_params(WIN, a.max_level)
+    lk = K.lk_params(WIN, a.max_level, sums=a.lk_sums)
     step_no = [0]
 
     def step():
@@ -730,7 +734,7 @@ def main():
     # the same step with maxLevel 3 (4 pyramid images), in case "4-level" is read that way
     ml3 = None
     if world == 1 and a.max_level == 4 and not a.skip_secondary:
-        lk3 = K.lk_params(WIN, 3)
+        lk3 = K.lk_params(WIN, 3, sums=a.lk_sums)
         n3 = max(3, a.steps // 4)
 
         def step3():

@@ -64,7 +64,20 @@ typedef struct {
     int device_p3p;                /* 0: P3P hypotheses solved on the host (bit-parity with a host-side
                                       solvePnPRansac); 1: solved by a HIP kernel, one thread per hypothesis
                                       (same algorithm, device libm: poses agree to ~1e-12) */
+    int lk_sums;                   /* how calcOpticalFlowPyrLK's five window sums per level are rounded when a call's
+                                      ktlvo_lk_params.sums is KTLVO_LK_SUMS_DEFAULT: KTLVO_LK_SUMS_EXACT or _TREE */
+    int p3p_polish;                /* Newton steps on the roots of the P3P quartic: 0 = none, the closed-form
+                                      roots of OpenCV 3's p3p.cpp as visualOdometry.cpp:206-208 reaches it */
 } ktlvo_config;
+
+/* The float accumulators of LKTrackerInvoker (A11, A12, A22, b1, b2: 441 integer-valued terms each) depend on
+ * the order of addition, which no parallel implementation shares with a serial one.
+ *   KTLVO_LK_SUMS_EXACT: every sum is the exact integer total of its terms, rounded to float once (to nearest
+ *     even).  Order-independent, so any implementation that sums exactly reproduces positions, status and
+ *     error bit for bit.
+ *   KTLVO_LK_SUMS_TREE: per-lane integer partials added as floats in a fixed 64-lane tree (four vector
+ *     instructions fewer per Gauss-Newton step); deterministic, within float rounding of any other order. */
+enum { KTLVO_LK_SUMS_DEFAULT = 0, KTLVO_LK_SUMS_TREE = 1, KTLVO_LK_SUMS_EXACT = 2 };
 
 /* cv::calcOpticalFlowPyrLK arguments as passed at featureTracking.cpp:205-209. */
 typedef struct {
@@ -73,6 +86,7 @@ typedef struct {
     int max_count;      /* TermCriteria count, 30 */
     double epsilon;     /* TermCriteria epsilon, 0.01 (squared internally, as OpenCV does) */
     double min_eig_thr; /* minEigThreshold default 1e-4 */
+    int sums;           /* KTLVO_LK_SUMS_*; 0 = the context's ktlvo_config.lk_sums */
 } ktlvo_lk_params;
 
 /* cv::GFTTDetector::create(100, 0.01, 10, 3, true, 0.0), featureTracking.cpp:103. */

@@ -108,7 +108,7 @@ class Frontend {
         // cv::TermCriteria semantics inside calcOpticalFlowPyrLK: a missing COUNT means 30, a missing EPS 0.01
         const int count = (criteria.type & TermCriteria::COUNT) ? (criteria.maxCount < 0 ? 0 : criteria.maxCount > 100 ? 100 : criteria.maxCount) : 30;
         const double eps = (criteria.type & TermCriteria::EPS) ? (criteria.epsilon < 0 ? 0. : criteria.epsilon > 10. ? 10. : criteria.epsilon) : 0.01;
-        const ktlvo_lk_params p = {winSize, maxLevel, count, eps, minEigThreshold};
+        const ktlvo_lk_params p = {winSize, maxLevel, count, eps, minEigThreshold, KTLVO_LK_SUMS_DEFAULT};
         const int n = (int)prevPts.size();
         nextPts.resize(n);
         status.resize(n);

@@ -96,6 +96,8 @@ _lib.orc_gao_quartic.restype = None
 _lib.orc_roots4.argtypes = [_f64p, _f64p]
 _lib.orc_set_lk_sum_mode.argtypes = [C.c_int]
 _lib.orc_set_lk_sum_mode.restype = None
+_lib.orc_get_lk_sum_mode.argtypes = []
+_lib.orc_get_lk_sum_mode.restype = C.c_int
 _lib.orc_p3p_set_polish.argtypes = [C.c_int]
 _lib.orc_p3p_set_polish.restype = None
 _lib.orc_project_score.argtypes = [_f32p, _f32p, C.c_int, _f64p, _f64p, C.c_float, C.c_void_p, C.c_void_p]
@@ -169,8 +171,12 @@ class Pyramid:
         return out
 
 
-def pyrlk(prev, nxt, pts, win=21, max_level=4, max_count=30, epsilon=0.01, min_eig_thr=1e-4, nthreads=1):
-    """prev/nxt: Pyramid objects (prev with derivatives) or 2-D uint8 arrays."""
+def pyrlk(prev, nxt, pts, win=21, max_level=4, max_count=30, epsilon=0.01, min_eig_thr=1e-4, nthreads=1, sums=None):
+    """prev/nxt: Pyramid objects (prev with derivatives) or 2-D uint8 arrays.  sums: the rounding of the window
+    sums for this call (see set_lk_sum_mode; None = the mode in force)."""
+    if sums is not None:
+        with lk_sum_mode(sums):
+            return pyrlk(prev, nxt, pts, win, max_level, max_count, epsilon, min_eig_thr, nthreads)
     if not isinstance(prev, Pyramid):
         prev = Pyramid(prev, max_level, win, True)
     if not isinstance(nxt, Pyramid):
@@ -295,9 +301,32 @@ def gao_quartic(a, b, p, q, r):
     return c
 
 
+SUMS_SERIAL, SUMS_FOUR_LANES, SUMS_PAIRWISE, SUMS_EXACT = 0, 1, 2, 3
+
+
 def set_lk_sum_mode(mode):
-    """0 serial (default), 1 four-lane, 2 pairwise: order of the float additions in the LK window sums."""
+    """Rounding of the LK window sums: 0 serial float accumulator (OpenCV's scalar path; default), 1 four float
+    accumulators, 2 pairwise float sum, 3 exact integer total rounded to float once (order-independent)."""
     _lib.orc_set_lk_sum_mode(int(mode))
+
+
+def get_lk_sum_mode():
+    return int(_lib.orc_get_lk_sum_mode())
+
+
+class lk_sum_mode:
+    """with lk_sum_mode(m): ... runs the block under sum mode m and restores the previous one."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_lk_sum_mode()
+        set_lk_sum_mode(self.mode)
+
+    def __exit__(self, *exc):
+        set_lk_sum_mode(self.prev)
+        return False
 
 
 def p3p_set_polish(newton_steps):

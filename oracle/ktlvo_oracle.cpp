@@ -168,13 +168,16 @@ static uint8_t *g_iter_log = nullptr; /* optional diagnostics: iterations per (l
 static int g_iter_log_n = 0;
 extern "C" void orc_set_iter_log(uint8_t *buf, int n_points) { g_iter_log = buf; g_iter_log_n = n_points; }
 
-/* Order in which the 441 float terms of each window sum are added.  0: one accumulator, raster order
- * (LKTrackerInvoker's scalar path; the oracle's reference behaviour).  1: four accumulators taken in turn
- * along a row and added at the end, the way a 4-lane SIMD build accumulates.  2: pairwise (tree) sum.
- * Modes 1 and 2 exist to measure how far the RESULT moves when only the rounding order of these sums
- * changes; every integer term is the same in all modes. */
+/* Order in which the 441 terms of each window sum are added.  0: one float accumulator, raster order
+ * (LKTrackerInvoker's scalar path; the oracle's reference behaviour).  1: four float accumulators taken in
+ * turn along a row and added at the end, the way a 4-lane SIMD build accumulates.  2: pairwise (tree) float
+ * sum.  3: the integer terms added exactly (int64) and the total converted to float once, round to nearest
+ * even: the one order-independent reading of the sum, which a parallel implementation can reproduce bit for
+ * bit whatever its own order of addition.  Modes 1 to 3 also measure how far the RESULT moves when only the
+ * rounding of these sums changes; every integer term is the same in all modes. */
 static int g_lk_sum_mode = 0;
-extern "C" void orc_set_lk_sum_mode(int mode) { g_lk_sum_mode = mode < 0 || mode > 2 ? 0 : mode; }
+extern "C" void orc_set_lk_sum_mode(int mode) { g_lk_sum_mode = mode < 0 || mode > 3 ? 0 : mode; }
+extern "C" int orc_get_lk_sum_mode(void) { return g_lk_sum_mode; }
 
 namespace {
 
@@ -182,9 +185,14 @@ namespace {
 template <int MODE>
 struct WinSum {
     float lane[4] = {0, 0, 0, 0};
-    float terms[32 * 32];
+    float terms[MODE == 2 ? 32 * 32 : 1];
+    long long exact = 0;
     int n = 0;
-    inline void add(float v, int x) {
+    /* the term is an integer (a product of two int16 values, or |diff|); OpenCV converts it to float and
+     * adds it to a float accumulator */
+    inline void add(int t, int x) {
+        if (MODE == 3) { exact += t; return; }
+        const float v = (float)t;
         if (MODE == 0) lane[0] += v;
         else if (MODE == 1) lane[x & 3] += v;
         else terms[n++] = v;
@@ -198,6 +206,7 @@ struct WinSum {
     inline float total() const {
         if (MODE == 0) return lane[0];
         if (MODE == 1) return (lane[0] + lane[2]) + (lane[1] + lane[3]);
+        if (MODE == 3) return (float)exact; /* one rounding, to nearest even */
         return n ? tree(terms, n) : 0.f;
     }
 };
@@ -250,9 +259,9 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
                 Ip[x] = (int16_t)ival;
                 dIp[0] = (int16_t)ixval;
                 dIp[1] = (int16_t)iyval;
-                sA11.add((float)(ixval * ixval), x);
-                sA12.add((float)(ixval * iyval), x);
-                sA22.add((float)(iyval * iyval), x);
+                sA11.add(ixval * ixval, x);
+                sA12.add(ixval * iyval, x);
+                sA22.add(iyval * iyval, x);
             }
         }
         const float iA11 = sA11.total(), iA12 = sA12.total(), iA22 = sA22.total();
@@ -288,8 +297,8 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
                 for (int x = 0; x < win; x++, dIp += 2) {
                     int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 +
                                        Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
-                    sb1.add((float)(diff * dIp[0]), x);
-                    sb2.add((float)(diff * dIp[1]), x);
+                    sb1.add(diff * dIp[0], x);
+                    sb2.add(diff * dIp[1], x);
                 }
             }
             const float ib1 = sb1.total(), ib2 = sb2.total();
@@ -327,7 +336,7 @@ void lk_level_range(const Level &I, const Level &J, const float *prevPts, float 
                 for (int x = 0; x < win; x++) {
                     int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 +
                                        Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
-                    serr.add(std::abs((float)diff), x);
+                    serr.add(std::abs(diff), x); /* |(float)diff|: diff is exact in float */
                 }
             }
             const float errval = serr.total();
@@ -351,7 +360,8 @@ extern "C" int orc_pyrlk(const orc_pyramid *prev, const orc_pyramid *next, const
     for (int i = 0; i < n; i++) { status[i] = 1; err[i] = 0; }
     nthreads = std::max(1, std::min(nthreads, n));
     if (win > 32) return -2; /* WinSum's term buffer */
-    auto range_fn = g_lk_sum_mode == 1 ? lk_level_range<1> : g_lk_sum_mode == 2 ? lk_level_range<2> : lk_level_range<0>;
+    auto range_fn = g_lk_sum_mode == 1 ? lk_level_range<1> : g_lk_sum_mode == 2 ? lk_level_range<2>
+                    : g_lk_sum_mode == 3 ? lk_level_range<3> : lk_level_range<0>;
     for (int level = maxLevel; level >= 0; level--) {
         const Level &I = prev->levels[level];
         const Level &J = next->levels[level];

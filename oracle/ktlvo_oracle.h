@@ -46,6 +46,7 @@ int orc_pyramid_deriv_copy(const orc_pyramid *p, int level, int16_t *dst /* 2*w*
  * raster order (default; LKTrackerInvoker's scalar path), 1 = four accumulators in turn along a row (a
  * 4-lane SIMD build), 2 = pairwise.  For measuring the sensitivity of LK results to rounding order. */
 void orc_set_lk_sum_mode(int mode);
+int orc_get_lk_sum_mode(void);
 
 /* cv::calcOpticalFlowPyrLK(prev, next, prevPts, nextPts, status, err, Size(win,win), maxLevel,
  * TermCriteria(COUNT|EPS, max_count, epsilon), flags=0, minEigThreshold).

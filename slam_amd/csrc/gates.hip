@@ -279,7 +279,7 @@ namespace ktlvo {
 int device_get_optical_flow(ktlvo_ctx *ctx, int slot_1, int slot_2, const float *d_f1, int n_cap, const int *d_n,
                             int y_threshold, float *d_f2, float *d_chk, int *d_keep_idx, int *d_n_keep,
                             const Gather &g) {
-    ktlvo_lk_params p = {ctx->cfg.win, ctx->cfg.max_level, 30, 0.01, 1e-4};
+    ktlvo_lk_params p = {ctx->cfg.win, ctx->cfg.max_level, 30, 0.01, 1e-4, KTLVO_LK_SUMS_DEFAULT};
     if (!slot_ok(ctx, slot_1) || !slot_ok(ctx, slot_2)) return KTLVO_ERR_INVALID;
     PairList fw, bw;
     fw.prev[0] = (uint16_t)slot_1; fw.next[0] = (uint16_t)slot_2;

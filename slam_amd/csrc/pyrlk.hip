@@ -109,6 +109,45 @@ __device__ __forceinline__ Sum2 wave_sum2(int a, int b) {
     return r;
 }
 
+// The same two sums EXACTLY: the integer total of each, rounded to float once (to nearest even), whatever the
+// order of addition -- what a serial int64 accumulator followed by one conversion yields.  Each lane's operand
+// is below 2^29 in magnitude (7 products of two values of at most 8161), the total of 64 of them below 2^35,
+// which no 32-bit register holds; but split into its low 16 bits L and the rest H = p - L (a multiple of
+// 2^16), either part of the total is exact in a float: sum L < 2^22, sum H a multiple of 2^16 below 2^35.
+// After the integer fold of lane pairs (as above) v_permlane16_swap puts the L and H parts of a's 32 lanes
+// into rows 0 and 1 and those of b's into rows 2 and 3, folding once more on the way (integers still: two H
+// parts stay below 2^31), one conversion and the row tree of wave_sum2 add up each row exactly, and the
+// row_bcast:15 add that joined two row sums there joins sum L and sum H here: the single rounding.
+// Four instructions more than wave_sum2.
+__device__ __forceinline__ Sum2 wave_sum2_exact(int a, int b) {
+    const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
+    const uint32_t p = sw[0] + sw[1];
+    uint32_t lo, hi;
+    asm("v_and_b32 %0, %2, %3\n\t"
+        "v_and_b32 %1, %2, %4"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(p), "s"(0xFFFFu), "s"(0xFFFF0000u));
+    // rows of lo: [l0 l1 l2 l3], of hi: [h0 h1 h2 h3] -> [l0 h0 l2 h2], [l1 h1 l3 h3]
+    const auto sx = __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+    float v = (float)(int)(sx[0] + sx[1]);
+    v = dpp_add<0xB1, 0xF>(v);
+    v = dpp_add<0x4E, 0xF>(v);
+    v = dpp_add<0x141, 0xF>(v);
+    v = dpp_add<0x140, 0xF>(v);
+    int ta, tb;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa\n\t" // rows 1, 3 (sum H) += lane 15 of rows 0, 2 (sum L)
+        "s_nop 1\n\t"
+        "v_readlane_b32 %0, %2, 31\n\t"
+        "v_readlane_b32 %1, %2, 63\n\t"
+        "s_nop 1" // before a VALU read of the SGPRs
+        : "=&s"(ta), "=&s"(tb), "+v"(v));
+    Sum2 r;
+    r.a = __int_as_float(ta);
+    r.b = __int_as_float(tb);
+    return r;
+}
+
 // The int16-pair dot products (v_dot2_i32_i16: a.lo * b.lo + a.hi * b.hi + c) are written as asm
 // blocks, because the builtin is selected as v_dot2c (dst == accumulator) and then costs a v_mov per
 // use whenever the accumulator input has to survive, as the template does here.  gfx950 needs three
@@ -407,7 +446,10 @@ struct LkResult {
     float x, y, err;
     int status;
 };
-template <int MAXL, class Args>
+// EXACT: the five window sums of a level (A11, A12, A22, b1, b2) are the exact integer totals rounded once
+// (wave_sum2_exact) instead of float sums in the order of the DPP tree; the error sum is exact either way
+// (its total stays below 2^24).
+template <int MAXL, bool EXACT, class Args>
 __device__ __forceinline__ LkResult lk_track(const Args &cr, const int max_level, const SlotDesc &SP, const SlotDesc &SN,
                                              const float ppx, const float ppy, const int lane) {
     const bool active = lane < 63;
@@ -505,9 +547,9 @@ __device__ __forceinline__ LkResult lk_track(const Args &cr, const int max_level
         }
         const Dot2 sxx = dot7x2(ixp, ixp, iyp);
         const int s11 = sxx.xy, s12 = sxx.xz, s22 = dot7(iyp, iyp);
-        const Sum2 sa = wave_sum2(s11, s12);
+        const Sum2 sa = EXACT ? wave_sum2_exact(s11, s12) : wave_sum2(s11, s12);
         const float A11 = sa.a * FLT_SCALE, A12 = sa.b * FLT_SCALE;
-        const float A22 = wave_sum((float)s22) * FLT_SCALE;
+        const float A22 = (EXACT ? wave_sum2_exact(s22, 0).a : wave_sum((float)s22)) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         // minEig = (A22 + A11 - sqrt((A11 - A22)^2 + 4 A12^2)) / (2 * 21 * 21) against the threshold.
         // The correctly rounded square root and division cost some thirty instructions, so they are
@@ -560,7 +602,7 @@ __device__ __forceinline__ LkResult lk_track(const Args &cr, const int max_level
             w = bilinear_weights<true>(frac);
             const Packed7 dp = sample_pack(cols, w, Ineg); // |sum| <= 255 * 32 * 512 + 511, |diff| <= 255 * 32
             const Dot2 bb = dot7x2(dp, ixp, iyp);
-            const Sum2 bs = wave_sum2(bb.xy, bb.xz);
+            const Sum2 bs = EXACT ? wave_sum2_exact(bb.xy, bb.xz) : wave_sum2(bb.xy, bb.xz);
             dx = (A12 * bs.b - A22 * bs.a) * Ds;
             dy = (A12 * bs.a - A11 * bs.b) * Ds;
             nx += dx; ny += dy;
@@ -658,7 +700,7 @@ __device__ __forceinline__ LkResult lk_track(const Args &cr, const int max_level
     return res;
 }
 
-template <int MAXL>
+template <int MAXL, bool EXACT>
 __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 8))) void pyrlk_track_w21(LkArgs a) {
     const int max_level = MAXL >= 0 ? MAXL : a.max_level;
     const int lane = threadIdx.x & 63;
@@ -688,7 +730,7 @@ __global__ __launch_bounds__(64 * LK_WPB) __attribute__((amdgpu_waves_per_eu(8, 
     const size_t gi = (size_t)a.next_off[pair] + f;
     const float ppx = a.prev[2 * gp], ppy = a.prev[2 * gp + 1];
 
-    const LkResult res = lk_track<MAXL>(a, max_level, SP, SN, ppx, ppy, lane);
+    const LkResult res = lk_track<MAXL, EXACT>(a, max_level, SP, SN, ppx, ppy, lane);
     if (lane == 0) {
         a.next[2 * gi] = res.x;
         a.next[2 * gi + 1] = res.y;
@@ -716,7 +758,7 @@ struct ChainArgs {
     int sLL, sLR, sCL, sCR;
     KTLVO_LK_CRITERIA
 };
-template <int MAXL>
+template <int MAXL, bool EXACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void pyrlk_frame_chain(ChainArgs a) {
     const int lane = threadIdx.x & 63;
     const int role = uniform((int)(threadIdx.x >> 6));
@@ -729,7 +771,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int t = 0; t < 2; t++) {
         const SlotDesc &SP = a.slots[t ? mid : a.sLL];
         const SlotDesc &SN = a.slots[t ? last : mid];
-        const LkResult res = lk_track<MAXL>(a, MAXL, SP, SN, x, y, lane);
+        const LkResult res = lk_track<MAXL, EXACT>(a, MAXL, SP, SN, x, y, lane);
         x = res.x; y = res.y;
         float *dst = t ? a.out[2 + role] : (role < 2 ? a.out[role] : nullptr);
         if (lane == 0 && dst) { dst[2 * f] = x; dst[2 * f + 1] = y; }
@@ -761,6 +803,12 @@ static void set_criteria(Args &a, const ktlvo_lk_params *p, int max_level) {
     }
 }
 
+// Which reading of the window sums a call asks for: its own setting, else the context's.
+static bool exact_sums(const ktlvo_ctx *ctx, const ktlvo_lk_params *p) {
+    const int m = p->sums != KTLVO_LK_SUMS_DEFAULT ? p->sums : ctx->cfg.lk_sums;
+    return m != KTLVO_LK_SUMS_TREE;
+}
+
 // d_out: B, C, D, E, CHK, CHKB as in pyrlk_frame_chain, n points each.  Returns KTLVO_ERR_UNSUPPORTED when the four
 // slots do not all hold the reference's five levels (the caller then takes the launch-per-stage route).
 int launch_frame_chain(ktlvo_ctx *ctx, int sLL, int sLR, int sCL, int sCR, const float *dA, int n, float *const d_out[6],
@@ -782,7 +830,8 @@ int launch_frame_chain(ktlvo_ctx *ctx, int sLL, int sLR, int sCL, int sCR, const
     a.sLL = sLL; a.sLR = sLR; a.sCL = sCL; a.sCR = sCR;
     set_criteria(a, p, 4);
     ProfScope ps(ctx, KTLVO_K_PYRLK);
-    hipLaunchKernelGGL(pyrlk_frame_chain<4>, dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+    if (exact_sums(ctx, p)) hipLaunchKernelGGL((pyrlk_frame_chain<4, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((pyrlk_frame_chain<4, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream, a);
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }
@@ -827,14 +876,22 @@ int launch_pyrlk_ex(ktlvo_ctx *ctx, const PairList &pairs, int n_pairs, const fl
     // the reference's maxLevel (featureTracking.cpp:208) gets the unrolled kernel
     // (level counts up to the reference's get a kernel of their own, with the level loop unrolled; deeper pyramids
     // share the looping one, which spills a few registers at eight waves per SIMD)
+    const dim3 block(64 * LK_WPB);
+#define KTLVO_LK_LAUNCH(L)                                                                                  \
+    do {                                                                                                    \
+        if (exact) hipLaunchKernelGGL((pyrlk_track_w21<L, true>), grid, block, 0, ctx->stream, a);           \
+        else hipLaunchKernelGGL((pyrlk_track_w21<L, false>), grid, block, 0, ctx->stream, a);                \
+    } while (0)
+    const bool exact = exact_sums(ctx, p);
     switch (max_level) {
-    case 4: hipLaunchKernelGGL(pyrlk_track_w21<4>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL(pyrlk_track_w21<3>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL(pyrlk_track_w21<2>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
-    case 1: hipLaunchKernelGGL(pyrlk_track_w21<1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
-    case 0: hipLaunchKernelGGL(pyrlk_track_w21<0>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(pyrlk_track_w21<-1>, grid, dim3(64 * LK_WPB), 0, ctx->stream, a); break;
+    case 4: KTLVO_LK_LAUNCH(4); break;
+    case 3: KTLVO_LK_LAUNCH(3); break;
+    case 2: KTLVO_LK_LAUNCH(2); break;
+    case 1: KTLVO_LK_LAUNCH(1); break;
+    case 0: KTLVO_LK_LAUNCH(0); break;
+    default: KTLVO_LK_LAUNCH(-1); break;
     }
+#undef KTLVO_LK_LAUNCH
     KTLVO_HIP(ctx, hipGetLastError());
     return KTLVO_OK;
 }

@@ -155,7 +155,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     float *dD = dDE, *dE = dD + 2 * (size_t)N, *dCHK = dE + 2 * (size_t)N, *dCHKB = dCHK + 2 * (size_t)N;
     int *dCnt = t->d_out, *dK1 = dCnt + 8, *dK2 = dK1 + N, *dK3 = dK2 + N;
     float *dU1 = (float *)(dK3 + N), *dU2 = dU1 + 2 * (size_t)N, *dU3 = dU2 + 2 * (size_t)N;
-    const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4}; // :195-197, :208-209
+    const ktlvo_lk_params lk = {c.win, c.max_level, 30, 0.01, 1e-4, KTLVO_LK_SUMS_DEFAULT}; // :195-197, :208-209
 
     // The reference makes 8 LK calls per frame.  A point's track depends on nothing but its two images
     // and its start, so the two forward calls inside getOpticalFlow (:205) repeat, on a subset, what

@@ -23,6 +23,7 @@ LIB_PATH = os.path.join(_HERE, "libktlvo_hip.so")
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 K_PYRDOWN, K_PYRLK, K_CORNER, K_RANSAC, K_SCHARR = 0, 1, 2, 3, 4
+LK_SUMS_DEFAULT, LK_SUMS_TREE, LK_SUMS_EXACT = 0, 1, 2
 
 
 class KtlvoError(RuntimeError):
@@ -45,12 +46,14 @@ class Config(C.Structure):
         ("ransac_iters", C.c_int), ("ransac_reproj", C.c_float), ("ransac_conf", C.c_double),
         ("max_hypotheses", C.c_int),
         ("device_p3p", C.c_int),
+        ("lk_sums", C.c_int),
+        ("p3p_polish", C.c_int),
     ]
 
 
 class LkParams(C.Structure):
     _fields_ = [("win", C.c_int), ("max_level", C.c_int), ("max_count", C.c_int), ("epsilon", C.c_double),
-                ("min_eig_thr", C.c_double)]
+                ("min_eig_thr", C.c_double), ("sums", C.c_int)]
 
 
 class GfttParams(C.Structure):
@@ -200,8 +203,8 @@ def default_config(**kw):
     return c
 
 
-def lk_params(win=21, max_level=4, max_count=30, epsilon=0.01, min_eig_thr=1e-4):
-    return LkParams(win, max_level, max_count, epsilon, min_eig_thr)
+def lk_params(win=21, max_level=4, max_count=30, epsilon=0.01, min_eig_thr=1e-4, sums=LK_SUMS_DEFAULT):
+    return LkParams(win, max_level, max_count, epsilon, min_eig_thr, sums)
 
 
 def gftt_params(max_corners=100, quality=0.01, min_dist=10.0, block_size=3, use_harris=1, harris_k=0.0):

@@ -34,8 +34,10 @@ def main():
     b[150:, 200:] = 90
     rng = np.random.default_rng(21)
     pts = np.stack([rng.uniform(-15, 335, 400), rng.uniform(-15, 255, 400)], 1).astype(np.float32)
-    nxt, st, err = O.pyrlk(a, b, pts)
-    np.savez_compressed(os.path.join(OUT, "lk_320x240.npz"), prev=a, next=b, pts=pts, out=nxt, status=st, err=err)
+    nxt, st, err = O.pyrlk(a, b, pts)                        # serial float sums (OpenCV's scalar order)
+    xn, xs, xe = O.pyrlk(a, b, pts, sums=O.SUMS_EXACT)       # exact integer totals rounded once
+    np.savez_compressed(os.path.join(OUT, "lk_320x240.npz"), prev=a, next=b, pts=pts, out=nxt, status=st, err=err,
+                        out_exact=xn, status_exact=xs, err_exact=xe)
 
     # 3. corners on ROIs of a 260x180 image (Harris k=0 as the reference, and min-eig)
     img = synth.texture_image(260, 180, seed=31, periods=(20.0, 8.0, 3.0))
@@ -65,7 +67,7 @@ def main():
     r = O.solve_pnp_ransac(Xw, uv, K)
     np.savez_compressed(os.path.join(OUT, "ransac_400.npz"), X3=Xw, x2=uv, K=K, rvec=r["rvec"], tvec=r["tvec"],
                         mask=r["mask"], n_inliers=np.int32(r["n_inliers"]), iters=np.int32(r["iters"]), log=r["log"])
-    # 5. inputs only: the frame of the randomised sweep (tests/test_gpu_fuzz.py, seed 1111, 240 cases, case 176:
+    # 5. the frame of the randomised sweep (tests/test_gpu_fuzz.py, seed 1111, 240 cases, case 176:
     #    164x140 white noise with saturated patches, shifted by whole pixels) on which LK results are most
     #    sensitive to the order of the float additions
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -78,8 +80,10 @@ def main():
                    [10.5, 10.5]]
         if i == 176:
             assert (w, h) == (164, 140)
-            np.savez_compressed(os.path.join(OUT, "lk_noise_164x140.npz"), prev=np.ascontiguousarray(a),
-                                next=np.ascontiguousarray(b), pts=pts)
+            a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+            xn, xs, xe = O.pyrlk(a, b, pts, sums=O.SUMS_EXACT)   # order-independent, so these outputs can be pinned
+            np.savez_compressed(os.path.join(OUT, "lk_noise_164x140.npz"), prev=a, next=b, pts=pts,
+                                out_exact=xn, status_exact=xs, err_exact=xe)
             break
     print("golden vectors written to", OUT)
 

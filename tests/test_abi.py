@@ -47,7 +47,7 @@ def test_default_config_matches_reference_constants(klib):
 
 def test_struct_layouts(klib):
     assert klib.IMAGE_POINT.itemsize == 12 and klib.DEPTH_POINT.itemsize == 24   # pointDefinition.h:18-42
-    assert C.sizeof(klib.LkParams) == 32 and C.sizeof(klib.Roi) == 16
+    assert C.sizeof(klib.LkParams) == 40 and C.sizeof(klib.Roi) == 16
 
 
 def test_create_fails_loudly_on_bad_config_or_missing_device(klib):
