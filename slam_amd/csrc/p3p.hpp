@@ -1,11 +1,21 @@
 // Minimal pose solver for the RANSAC kernel of cv::solvePnPRansac(..., SOLVEPNP_P3P) as the
-// reference calls it (visualOdometry.cpp:124, 206-208): three 3-D/2-D correspondences give up to
-// four camera poses, a fourth correspondence picks one (cv::solvePnP's P3P rule).
+// reference calls it (visualOdometry.cpp:122-127 selects the flag, :206-208 is the call): three
+// 3-D/2-D correspondences give up to four camera poses, a fourth correspondence picks one
+// (cv::solvePnP's P3P rule).
 //
-// Formulation (Grunert / Fischler-Bolles family): with s_i the distances of the three points from
-// the camera centre, put s2 = u s1, s3 = v s1.  The three law-of-cosines equations give
-// u = N(v) / D(v) and one quartic in v; each positive root yields the three camera-frame points,
-// and the pose follows from aligning the two triangles' orthonormal triads.
+// OpenCV 3's solver for that flag is Gao, Hou, Tang, Cheng, "Complete solution classification for the
+// perspective-three-point problem" (PAMI 25(8), 2003), and so is this one: with X, Y, Z the distances
+// from the camera centre to the three points and x = X/Z, y = Y/Z, the cosine-law equations reduce to
+// one quartic in x with closed-form coefficients, y follows rationally, the quartic is solved in closed
+// form (Ferrari split through one root of the resolvent cubic, Cardano or the trigonometric form) and
+// the pose is the absolute orientation of the two triangles (Horn's unit quaternion).
+// The closed-form roots are part of the reference's RESULT: they are not polished, so near a multiple
+// root they carry errors many orders above rounding, and which hypothesis then collects the most
+// inliers at a 0.1 px threshold depends on them.  The quartic's coefficients and the root formulas
+// therefore keep the operation order of the published closed forms (every product and sum rounds where
+// theirs does); `polish` > 0 adds that many Newton steps per root, the refinement later OpenCV releases
+// apply.  What is well conditioned (the alignment) is written for one thread per hypothesis: fixed trip
+// counts, no recursion, no heap, everything in registers or a few dozen doubles of scratch.
 // Everything is double precision and usable from host and device code.
 #pragma once
 
@@ -25,203 +35,232 @@ struct Pose {
     double t[3];
 };
 
-KTLVO_HD int quadratic(double a, double b, double c, double x[2]) {
-    if (a == 0) {
-        if (b == 0) return 0;
-        x[0] = -c / b;
-        return 1;
+// One root of the monic resolvent cubic y^3 + b y^2 + c y + d: with three real roots the one the
+// trigonometric form gives at theta / 3, otherwise the real one by Cardano.  (2 R)^(1/3) of a negative
+// R is NaN, as with the library pow the closed form is written on; the quartic then has no roots.
+KTLVO_HD double resolvent_root(double b, double c, double d) {
+    const double b2 = b * b;
+    const double Q = (3 * c - b2) / 9;
+    const double R = (9 * b * c - 27 * d - 2 * b * b2) / 54;
+    const double Q3 = Q * Q * Q;
+    const double D = Q3 + R * R;
+    const double b_3 = (1. / 3.) * b;
+    if (Q == 0) return R == 0 ? -b_3 : pow(2 * R, 1 / 3.0) - b_3;
+    if (D <= 0) {
+        const double theta = acos(R / sqrt(-Q3));
+        return 2 * sqrt(-Q) * cos(theta / 3.0) - b_3;
     }
-    const double d = b * b - 4 * a * c;
-    if (d < 0) return 0;
-    const double sd = sqrt(d);
-    const double q = -0.5 * (b + (b >= 0 ? sd : -sd));
-    if (q == 0) { x[0] = x[1] = 0; return 2; }
-    x[0] = q / a;
-    x[1] = c / q;
-    return 2;
+    const double AD = pow(fabs(R) + sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    const double BD = (AD == 0) ? 0 : -Q / AD;
+    return AD + BD - b_3;
 }
 
-// largest real root of x^3 + a x^2 + b x + c
-KTLVO_HD double cubic_top_root(double a, double b, double c) {
-    const double a3 = a / 3.0;
-    const double p = b - a * a3, q = 2 * a3 * a3 * a3 - a3 * b + c;
-    const double disc = q * q / 4 + p * p * p / 27;
-    double t;
-    if (disc > 0) {
-        const double sd = sqrt(disc);
-        t = cbrt(-q / 2 + sd) + cbrt(-q / 2 - sd);
-    } else if (p == 0) {
-        t = cbrt(-q);
-    } else {
-        const double m = 2 * sqrt(-p / 3);
-        double arg = 3 * q / (p * m);
-        arg = arg < -1.0 ? -1.0 : arg > 1.0 ? 1.0 : arg;
-        t = m * cos(acos(arg) / 3);
-    }
-    double x = t - a3;
-    for (int i = 0; i < 3; i++) {
-        const double f = ((x + a) * x + b) * x + c, df = (3 * x + 2 * a) * x + b;
-        if (df == 0) break;
-        x -= f / df;
-    }
-    return x;
-}
-
-// real roots of k[0] + k[1] x + ... + k[4] x^4 (Ferrari), polished by Newton steps
-KTLVO_HD int quartic(const double k[5], double roots[4]) {
-    if (fabs(k[4]) < 1e-14 * (fabs(k[3]) + fabs(k[2]) + fabs(k[1]) + fabs(k[0]))) return 0;
-    const double a = k[3] / k[4], b = k[2] / k[4], c = k[1] / k[4], d = k[0] / k[4];
-    const double a2 = a * a;
-    const double p = b - 3 * a2 / 8, q = c - a * b / 2 + a2 * a / 8;
-    const double r = d - a * c / 4 + a2 * b / 16 - 3 * a2 * a2 / 256;
-    double y[4];
-    int n = 0;
-    if (fabs(q) < 1e-14 * (1 + fabs(p) + fabs(r))) {
-        double t[2];
-        const int nt = quadratic(1, p, r, t);
-        for (int i = 0; i < nt; i++)
-            if (t[i] >= 0) {
-                const double s = sqrt(t[i]);
-                y[n++] = s;
-                y[n++] = -s;
-            }
-    } else {
-        const double m = cubic_top_root(p, (p * p - 4 * r) / 4, -q * q / 8);
-        if (m <= 0) return 0;
-        const double s2m = sqrt(2 * m);
-        double t[2];
-        int nt = quadratic(1, -s2m, p / 2 + m + q / (2 * s2m), t);
-        for (int i = 0; i < nt; i++) y[n++] = t[i];
-        nt = quadratic(1, s2m, p / 2 + m - q / (2 * s2m), t);
-        for (int i = 0; i < nt; i++) y[n++] = t[i];
-    }
-    for (int i = 0; i < n; i++) {
-        double x = y[i] - a / 4;
-        for (int it = 0; it < 2; it++) {
-            const double f = (((k[4] * x + k[3]) * x + k[2]) * x + k[1]) * x + k[0];
-            const double df = ((4 * k[4] * x + 3 * k[3]) * x + 2 * k[2]) * x + k[1];
-            if (df == 0) break;
-            x -= f / df;
+// Real roots of a x^4 + b x^3 + c x^2 + d x + e, a != 0, in closed form (Ferrari); multiple roots are
+// listed as often as the two quadratics yield them.
+KTLVO_HD int quartic_roots(double a, double b, double c, double d, double e, double x[4]) {
+    const double inv_a = 1. / a;
+    b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+    const double b2 = b * b, bc = b * c, b3 = b2 * b;
+    const double r0 = resolvent_root(-c, d * b - 4 * e, 4 * c * e - d * d - b2 * e);
+    const double R2 = 0.25 * b2 - c + r0;
+    if (R2 < 0) return 0;
+    const double R = sqrt(R2);
+    const double inv_R = 1. / R;
+    double D2, E2;
+    if (R < 10E-12) {
+        const double temp = r0 * r0 - 4 * e;
+        if (temp < 0) {
+            D2 = E2 = -1;
+        } else {
+            const double sq = sqrt(temp);
+            D2 = 0.75 * b2 - 2 * c + 2 * sq;
+            E2 = D2 - 4 * sq;
         }
-        roots[i] = x;
+    } else {
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+        D2 = u + v;
+        E2 = u - v;
+    }
+    const double b_4 = 0.25 * b, R_2 = 0.5 * R;
+    int n = 0;
+    if (D2 >= 0) {
+        const double Dq = sqrt(D2);
+        x[0] = R_2 + 0.5 * Dq - b_4;
+        x[1] = x[0] - Dq;
+        n = 2;
+    }
+    if (E2 >= 0) {
+        const double Eq = sqrt(E2);
+        x[n] = -R_2 + 0.5 * Eq - b_4;
+        x[n + 1] = x[n] - Eq;
+        n += 2;
     }
     return n;
 }
 
-KTLVO_HD double dot(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-KTLVO_HD void cross(const double a[3], const double b[3], double o[3]) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-KTLVO_HD bool unit(double a[3]) {
-    const double n = sqrt(dot(a, a));
-    if (n < 1e-300) return false;
-    a[0] /= n; a[1] /= n; a[2] /= n;
-    return true;
-}
-// E = [e1 e2 e3] (columns): e1 along P1P2, e3 normal of the triangle, e2 = e3 x e1
-KTLVO_HD bool triad(const double P1[3], const double P2[3], const double P3[3], double E[9]) {
-    double e1[3] = {P2[0] - P1[0], P2[1] - P1[1], P2[2] - P1[2]};
-    const double w[3] = {P3[0] - P1[0], P3[1] - P1[1], P3[2] - P1[2]};
-    double e2[3], e3[3];
-    if (!unit(e1)) return false;
-    cross(e1, w, e3);
-    if (!unit(e3)) return false;
-    cross(e3, e1, e2);
-    for (int i = 0; i < 3; i++) { E[3 * i] = e1[i]; E[3 * i + 1] = e2[i]; E[3 * i + 2] = e3[i]; }
-    return true;
-}
-
-// X: three world points (9), uv: their pixels (6), K = fx, fy, cx, cy. Returns the pose count.
-KTLVO_HD int solve3(const double X[9], const double uv[6], const double K[4], Pose out[4]) {
-    double f[3][3];
-    for (int i = 0; i < 3; i++) {
-        f[i][0] = (uv[2 * i] - K[2]) / K[0];
-        f[i][1] = (uv[2 * i + 1] - K[3]) / K[1];
-        f[i][2] = 1.0;
-        unit(f[i]);
-    }
-    const double *P1 = X, *P2 = X + 3, *P3 = X + 6;
-    double d[3];
-    d[0] = P2[0] - P3[0]; d[1] = P2[1] - P3[1]; d[2] = P2[2] - P3[2];
-    const double a2 = dot(d, d);
-    d[0] = P1[0] - P3[0]; d[1] = P1[1] - P3[1]; d[2] = P1[2] - P3[2];
-    const double b2 = dot(d, d);
-    d[0] = P1[0] - P2[0]; d[1] = P1[1] - P2[1]; d[2] = P1[2] - P2[2];
-    const double c2 = dot(d, d);
-    if (a2 < 1e-20 || b2 < 1e-20 || c2 < 1e-20) return 0;
-    const double ca = dot(f[1], f[2]), cb = dot(f[0], f[2]), cg = dot(f[0], f[1]);
-    double Ew[9];
-    if (!triad(P1, P2, P3, Ew)) return 0;
-
-    // A(v) = 1 - 2 cb v + v^2; N(v) = (a2 - c2) A + b2 (1 - v^2); D(v) = 2 b2 (cg - ca v)
-    // quartic: b2 (D^2 + N^2 - 2 cg N D) - c2 A D^2
-    const double A[3] = {1, -2 * cb, 1};
-    const double N[3] = {(a2 - c2) + b2, (a2 - c2) * A[1], (a2 - c2) - b2};
-    const double D[2] = {2 * b2 * cg, -2 * b2 * ca};
-    const double DD[3] = {D[0] * D[0], 2 * D[0] * D[1], D[1] * D[1]};
-    double NN[5] = {0, 0, 0, 0, 0}, ND[4] = {0, 0, 0, 0}, ADD[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) {
-            NN[i + j] += N[i] * N[j];
-            ADD[i + j] += A[i] * DD[j];
+// Gao et al.: the distances (X, Y, Z) from the camera centre to the three points, up to four triples.
+// dist = |P1 P2|, |P0 P2|, |P0 P1|; cosv = the cosines between the bearings of the same pairs.
+KTLVO_HD int gao_distances(const double dist[3], const double cosv[3], int polish, double len[4][3]) {
+    const double p = cosv[0] * 2, q = cosv[1] * 2, r = cosv[2] * 2;
+    const double inv_d22 = 1. / (dist[2] * dist[2]);
+    const double a = inv_d22 * (dist[0] * dist[0]);
+    const double b = inv_d22 * (dist[1] * dist[1]);
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    const double pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return 0; // the four points (camera centre included) are coplanar
+    const double ab = a * b, a_2 = 2 * a;
+    const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return 0;
+    const double a_4 = 4 * a;
+    const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    const double b0 = b * temp * temp;
+    if (b0 == 0) return 0;
+    double xs[4];
+    const int n = quartic_roots(A, B, C, D, E, xs);
+    for (int i = 0; i < n; i++)
+        for (int it = 0; it < polish; it++) {
+            const double x = xs[i];
+            const double f = (((A * x + B) * x + C) * x + D) * x + E, df = ((4 * A * x + 3 * B) * x + 2 * C) * x + D;
+            if (df == 0) break;
+            xs[i] = x - f / df;
         }
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 2; j++) ND[i + j] += N[i] * D[j];
-    double Q[5], qs = 0;
-    for (int i = 0; i < 5; i++) {
-        const double dd = i < 3 ? DD[i] : 0, nd = i < 4 ? ND[i] : 0;
-        Q[i] = b2 * (dd + NN[i] - 2 * cg * nd) - c2 * ADD[i];
-        qs = fabs(Q[i]) > qs ? fabs(Q[i]) : qs;
-    }
-    if (qs == 0) return 0;
-    for (int i = 0; i < 5; i++) Q[i] /= qs;
-
-    double roots[4];
-    const int nr = quartic(Q, roots);
+    // y = b1(x) / b0; the sub-expressions of b1 that do not depend on the root are formed once, and the sums that
+    // run across them keep their order
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+    const double inv_b0 = 1. / b0;
+    const double k2 = 1 - a - b, k1 = q * a - q;
+    const double c3 = r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1);
+    const double c2 = r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2);
+    const double c1 = r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) +
+                      r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) + pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b);
+    const double t1 = 2 * r3q * (a_2 - b - a2 + ab - 1);
+    const double t2 = pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2);
+    const double t3 = p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1));
     int ns = 0;
-    for (int ri = 0; ri < nr && ns < 4; ri++) {
-        const double v = roots[ri];
-        if (!(v > 0)) continue;
-        const double Dv = D[0] + D[1] * v;
-        if (fabs(Dv) < 1e-12 * b2) continue;
-        const double u = (N[0] + (N[1] + N[2] * v) * v) / Dv;
-        if (!(u > 0)) continue;
-        const double Av = A[0] + (A[1] + A[2] * v) * v;
-        if (!(Av > 0)) continue;
-        const double s1 = sqrt(b2 / Av), s2 = u * s1, s3 = v * s1;
-        const double C1[3] = {s1 * f[0][0], s1 * f[0][1], s1 * f[0][2]};
-        const double C2[3] = {s2 * f[1][0], s2 * f[1][1], s2 * f[1][2]};
-        const double C3[3] = {s3 * f[2][0], s3 * f[2][1], s3 * f[2][2]};
-        double Ec[9];
-        if (!triad(C1, C2, C3, Ec)) continue;
-        Pose &P = out[ns];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++) {
-                double s = 0;
-                for (int k = 0; k < 3; k++) s += Ec[3 * i + k] * Ew[3 * j + k];
-                P.R[3 * i + j] = s;
-            }
-        for (int i = 0; i < 3; i++)
-            P.t[i] = C1[i] - (P.R[3 * i] * P1[0] + P.R[3 * i + 1] * P1[1] + P.R[3 * i + 2] * P1[2]);
-        bool dup = false; // a double root gives the same pose twice
-        for (int q = 0; q < ns && !dup; q++) {
-            double e = 0;
-            for (int i = 0; i < 9; i++) e = fmax(e, fabs(out[q].R[i] - P.R[i]));
-            for (int i = 0; i < 3; i++) e = fmax(e, fabs(out[q].t[i] - P.t[i]) / (1 + fabs(P.t[i])));
-            dup = e < 1e-9;
-        }
-        if (!dup) ns++;
+    for (int i = 0; i < n; i++) {
+        const double x = xs[i];
+        if (x <= 0) continue;
+        const double x2 = x * x;
+        const double b1 = (k2 * x2 + k1 * x + 1 - a + b) * ((c3 * x + c2) * x2 + c1 * x + t1 + t2 + t3);
+        if (b1 <= 0) continue;
+        const double y = inv_b0 * b1;
+        const double v = x2 + y * y - x * y * r;
+        if (v <= 0) continue;
+        const double Z = dist[2] / sqrt(v);
+        len[ns][0] = x * Z;
+        len[ns][1] = y * Z;
+        len[ns][2] = Z;
+        ns++;
     }
     return ns;
 }
 
+// Unit eigenvector of the largest eigenvalue of a symmetric 4x4 matrix (upper triangle of N used): cyclic Jacobi
+// rotations, a fixed number of sweeps (convergence is quadratic: after five sweeps the off-diagonal mass of a
+// 4x4 matrix is below rounding, further sweeps change nothing).
+KTLVO_HD void top_eigenvector4(double N[4][4], double q[4]) {
+    double U[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) U[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 8; sweep++)
+        for (int pi = 0; pi < 3; pi++)
+            for (int qi = pi + 1; qi < 4; qi++) {
+                const double apq = N[pi][qi];
+                if (apq == 0) continue;
+                const double theta = (N[qi][qi] - N[pi][pi]) / (2 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 4; k++) {
+                    const double akp = N[k][pi], akq = N[k][qi];
+                    N[k][pi] = c * akp - s * akq;
+                    N[k][qi] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double apk = N[pi][k], aqk = N[qi][k];
+                    N[pi][k] = c * apk - s * aqk;
+                    N[qi][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 4; k++) {
+                    const double ukp = U[k][pi], ukq = U[k][qi];
+                    U[k][pi] = c * ukp - s * ukq;
+                    U[k][qi] = s * ukp + c * ukq;
+                }
+            }
+    int im = 0;
+    for (int i = 1; i < 4; i++)
+        if (N[i][i] > N[im][im]) im = i;
+    for (int i = 0; i < 4; i++) q[i] = U[i][im];
+}
+
+// Horn's absolute orientation of three point pairs: cam_i = R world_i + t in the least-squares sense.
+KTLVO_HD void align3(const double cam[3][3], const double world[3][3], Pose &P) {
+    double Cc[3], Cw[3];
+    for (int j = 0; j < 3; j++) {
+        Cc[j] = (cam[0][j] + cam[1][j] + cam[2][j]) / 3;
+        Cw[j] = (world[0][j] + world[1][j] + world[2][j]) / 3;
+    }
+    double s[3][3]; // cross-covariance of world (rows) and camera (columns) coordinates
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            s[i][j] = (world[0][i] * cam[0][j] + world[1][i] * cam[1][j] + world[2][i] * cam[2][j]) / 3 - Cc[j] * Cw[i];
+    double N[4][4];
+    N[0][0] = s[0][0] + s[1][1] + s[2][2];
+    N[1][1] = s[0][0] - s[1][1] - s[2][2];
+    N[2][2] = s[1][1] - s[2][2] - s[0][0];
+    N[3][3] = s[2][2] - s[0][0] - s[1][1];
+    N[1][0] = N[0][1] = s[1][2] - s[2][1];
+    N[2][0] = N[0][2] = s[2][0] - s[0][2];
+    N[3][0] = N[0][3] = s[0][1] - s[1][0];
+    N[2][1] = N[1][2] = s[1][0] + s[0][1];
+    N[3][1] = N[1][3] = s[2][0] + s[0][2];
+    N[3][2] = N[2][3] = s[2][1] + s[1][2];
+    double q[4];
+    top_eigenvector4(N, q);
+    const double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
+    double *R = P.R;
+    R[0] = q02 + q12 - q22 - q32; R[1] = 2. * (q[1] * q[2] - q[0] * q[3]); R[2] = 2. * (q[1] * q[3] + q[0] * q[2]);
+    R[3] = 2. * (q[1] * q[2] + q[0] * q[3]); R[4] = q02 + q22 - q12 - q32; R[5] = 2. * (q[2] * q[3] - q[0] * q[1]);
+    R[6] = 2. * (q[1] * q[3] - q[0] * q[2]); R[7] = 2. * (q[2] * q[3] + q[0] * q[1]); R[8] = q02 + q32 - q12 - q22;
+    for (int i = 0; i < 3; i++) P.t[i] = Cc[i] - (R[3 * i] * Cw[0] + R[3 * i + 1] * Cw[1] + R[3 * i + 2] * Cw[2]);
+}
+
+// X: three world points (9), uv: their pixels (6), K = fx, fy, cx, cy. Returns the pose count.
+KTLVO_HD int solve3(const double X[9], const double uv[6], const double K[4], int polish, Pose out[4]) {
+    const double inv_fx = 1. / K[0], inv_fy = 1. / K[1], cx_fx = K[2] / K[0], cy_fy = K[3] / K[1];
+    double m[3][3], world[3][3]; // unit bearings, world points
+    for (int i = 0; i < 3; i++) {
+        const double mu = inv_fx * uv[2 * i] - cx_fx, mv = inv_fy * uv[2 * i + 1] - cy_fy;
+        const double mk = 1. / sqrt(mu * mu + mv * mv + 1);
+        m[i][0] = mu * mk; m[i][1] = mv * mk; m[i][2] = mk;
+        world[i][0] = X[3 * i]; world[i][1] = X[3 * i + 1]; world[i][2] = X[3 * i + 2];
+    }
+    double dist[3], cosv[3]; // pairs (1,2), (0,2), (0,1)
+    for (int k = 0; k < 3; k++) {
+        const int i = k == 0 ? 1 : 0, j = k == 2 ? 1 : 2;
+        const double dx = world[i][0] - world[j][0], dy = world[i][1] - world[j][1], dz = world[i][2] - world[j][2];
+        dist[k] = sqrt(dx * dx + dy * dy + dz * dz);
+        cosv[k] = m[i][0] * m[j][0] + m[i][1] * m[j][1] + m[i][2] * m[j][2];
+    }
+    double len[4][3];
+    const int n = gao_distances(dist, cosv, polish, len);
+    for (int s = 0; s < n; s++) {
+        double cam[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) cam[i][j] = len[s][i] * m[i][j];
+        align3(cam, world, out[s]);
+    }
+    return n;
+}
+
 // Four correspondences: candidates from the first three, the fourth picks the one with the
 // smallest reprojection error.
-KTLVO_HD bool solve4(const double X[12], const double uv[8], const double K[4], Pose &best) {
+KTLVO_HD bool solve4(const double X[12], const double uv[8], const double K[4], int polish, Pose &best) {
     Pose cand[4];
-    const int n = solve3(X, uv, K, cand);
+    const int n = solve3(X, uv, K, polish, cand);
     if (n == 0) return false;
     int ns = 0;
     double min_reproj = 0;

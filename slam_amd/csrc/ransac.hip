@@ -58,10 +58,10 @@ __global__ __launch_bounds__(256) void ransac_score(const float *X3, const float
 }
 
 // Minimal solver on the device: thread h takes index quadruple h, solves P3P in double
-// (p3p.hpp, the same code the host path runs), converts R -> rvec -> R as PnPRansacCallback's model
+// (p3p.hpp, the same code the host path runs; Gao's closed form, `polish` Newton steps on its roots), converts R -> rvec -> R as PnPRansacCallback's model
 // round trip does, and leaves R|t, rvec and a validity flag for the scoring launch.
 __global__ __launch_bounds__(64) void ransac_p3p(const float *X3, const float *x2, const int *idx, int H, double fx,
-                                                 double fy, double cx, double cy, double *Rt, double *rv,
+                                                 double fy, double cx, double cy, int polish, double *Rt, double *rv,
                                                  unsigned char *valid) {
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= H) return;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void ransac_p3p(const float *X3, const float *x
         us[2 * i] = x2[2 * k]; us[2 * i + 1] = x2[2 * k + 1];
     }
     p3p::Pose P;
-    const bool ok = p3p::solve4(Xs, us, K, P);
+    const bool ok = p3p::solve4(Xs, us, K, polish, P);
     valid[h] = ok ? 1 : 0;
     double r[3] = {0, 0, 0}, R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (ok) {
@@ -204,6 +204,7 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
     const double K[4] = {ctx->cfg.fx, ctx->cfg.fy, ctx->cfg.cx, ctx->cfg.cy};
     const double threshold = reproj_err;
     const float thr_sq = (float)(threshold * threshold);
+    const int polish = ctx->cfg.p3p_polish < 0 ? 0 : ctx->cfg.p3p_polish > 8 ? 8 : ctx->cfg.p3p_polish;
 
     // 1. all index quadruples, in the order cv::RNG((uint64)-1) hands them to getSubset
     std::vector<int> idx((size_t)4 * H);
@@ -239,7 +240,7 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
         KTLVO_HIP(ctx, hipMemcpyAsync(b.d_X3, hp, b.o_x + (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
         KTLVO_HIP(ctx, hipMemcpyAsync(b.d_idx, idx.data(), (size_t)H * 16, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(ransac_p3p, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, b.d_X3, b.d_x2, b.d_idx, H, K[0],
-                           K[1], K[2], K[3], b.d_Rt, b.d_rv, b.d_valid);
+                           K[1], K[2], K[3], polish, b.d_Rt, b.d_rv, b.d_valid);
         KTLVO_HIP(ctx, hipGetLastError());
     } else {
         double *Rt_h = (double *)(hp + b.o_Rt);
@@ -254,7 +255,7 @@ extern "C" int ktlvo_solve_pnp_ransac(ktlvo_ctx *ctx, const float *X3, const flo
                 us[2 * i] = x2[2 * k]; us[2 * i + 1] = x2[2 * k + 1];
             }
             p3p::Pose P;
-            if (!p3p::solve4(Xs, us, K, P)) continue;
+            if (!p3p::solve4(Xs, us, K, polish, P)) continue;
             valid_h[it] = 1;
             p3p::rodrigues_m2v(P.R, &rv[3 * (size_t)it]);
             p3p::rodrigues_v2m(&rv[3 * (size_t)it], &Rt_h[12 * (size_t)it]);

@@ -242,32 +242,42 @@ def test_gates_are_one_sided():
 
 def test_p3p_recovers_pose():
     """Gao P3P on exact projections of random poses.  With the closed-form roots as they come (OpenCV 3.x) a
-    few per cent of the triples are resolved to 1e-6 .. 1e-3 only (depths up to 40 m over a 1 m motion are
-    badly conditioned and the closed forms lose digits); the bars are therefore quantiles."""
-    rng = np.random.default_rng(1)
+    few per cent of the triples are resolved to 1e-6 .. 1e-3 only and now and then one not at all (depths up to
+    40 m over a 1 m motion are badly conditioned and the closed forms lose digits: 1 of 296 here comes out 0.5
+    off), so the bars on that mode are quantiles; with two Newton steps on the roots every case has a hard bound."""
     K = np.array([707.0912, 707.0912, 601.8873, 183.1104])
-    e3, e4 = [], []
-    for _ in range(300):
-        rv = rng.normal(size=3) * 0.3
-        R = O.rodrigues_v2m(rv)
-        t = rng.normal(size=3) * np.array([0.5, 0.2, 1.0])
-        Xw = np.stack([rng.uniform(-8, 8, 4), rng.uniform(-2, 2, 4), rng.uniform(4, 40, 4)], 1)
-        Xc = Xw @ R.T + t
-        if (Xc[:, 2] < 1).any():
-            continue
-        uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
-        Rs, ts = O.p3p(Xw[:3], uv[:3], K)
-        assert 1 <= len(Rs) <= 4
-        e3.append(min(max(np.abs(Ri - R).max(), np.abs(ti - t).max()) for Ri, ti in zip(Rs, ts)))
-        for Ri in Rs:
-            assert np.abs(Ri @ Ri.T - np.eye(3)).max() < 1e-9 and np.linalg.det(Ri) > 0
-        ok, R4, t4 = O.solve_p3p4(Xw, uv, K)
-        assert ok
-        e4.append(max(np.abs(R4 - R).max(), np.abs(t4 - t).max()))
-        assert np.abs(O.rodrigues_m2v(R) - rv).max() < 1e-9
-    assert len(e3) > 200
-    for e in (np.array(e3), np.array(e4)):
-        assert np.median(e) < 1e-9 and np.percentile(e, 85) < 1e-6 and np.percentile(e, 97) < 1e-2
+    for polish in (0, 2):
+        O.p3p_set_polish(polish)
+        try:
+            rng = np.random.default_rng(1)
+            e3, e4 = [], []
+            for _ in range(300):
+                rv = rng.normal(size=3) * 0.3
+                R = O.rodrigues_v2m(rv)
+                t = rng.normal(size=3) * np.array([0.5, 0.2, 1.0])
+                Xw = np.stack([rng.uniform(-8, 8, 4), rng.uniform(-2, 2, 4), rng.uniform(4, 40, 4)], 1)
+                Xc = Xw @ R.T + t
+                if (Xc[:, 2] < 1).any():
+                    continue
+                uv = np.stack([K[0] * Xc[:, 0] / Xc[:, 2] + K[2], K[1] * Xc[:, 1] / Xc[:, 2] + K[3]], 1)
+                Rs, ts = O.p3p(Xw[:3], uv[:3], K)
+                assert 1 <= len(Rs) <= 4
+                e3.append(min(max(np.abs(Ri - R).max(), np.abs(ti - t).max()) for Ri, ti in zip(Rs, ts)))
+                for Ri in Rs:
+                    assert np.abs(Ri @ Ri.T - np.eye(3)).max() < 1e-9 and np.linalg.det(Ri) > 0
+                ok, R4, t4 = O.solve_p3p4(Xw, uv, K)
+                assert ok
+                e4.append(max(np.abs(R4 - R).max(), np.abs(t4 - t).max()))
+                assert np.abs(O.rodrigues_m2v(R) - rv).max() < 1e-9
+        finally:
+            O.p3p_set_polish(0)
+        assert len(e3) > 200
+        for e in (np.array(e3), np.array(e4)):
+            assert np.median(e) < 1e-9 and np.percentile(e, 85) < 1e-6 and np.percentile(e, 97) < 1e-2
+            if polish:
+                assert e.max() < 1e-3 and np.percentile(e, 99) < 1e-5      # every case, polished
+            else:
+                assert e.max() < 1.0 and (e > 1e-2).sum() <= 2             # the closed forms' failures are rare
 
 
 def test_ransac_pnp_finds_pose_and_is_deterministic():
