@@ -641,32 +641,76 @@ def main():
         (xy0, _), = ctx.detect_gftt(prev_slots[0], [(0, 0, W, H)], gp)
         assert int(cc[0]) == len(xy0) and np.array_equal(d_cxy[0, :len(xy0)].cpu().numpy(), xy0)
         # the whole stream step: detect on the first frames, build the pyramids, track the detected corners (frames
-        # short of NF corners at this spacing track their list's unused tail as well; only real corners are counted)
+        # short of NF corners at this spacing track their list's unused tail as well; only real corners are counted).
+        # Two arrangements: the three calls one after the other, and ktlvo_detect_build_frames_dev, which runs the
+        # pyramid build on a side stream beside the detection.
         o_next, o_status, o_err = outs[0]
 
-        def full_step():
-            detect_all()
-            ctx.build_pyramids(slots)
+        def full_step(side_by_side):
+            if side_by_side:
+                ctx.detect_build_frames_dev(prev_slots, gp, d_cxy.data_ptr(), d_cr.data_ptr(), d_cc.data_ptr(), NF, slots)
+            else:
+                detect_all()
+                ctx.build_pyramids(slots)
             ctx.pyrlk_batch_dev(prev_slots, next_slots, d_cxy.data_ptr(), NF, o_next.data_ptr(), o_status.data_ptr(),
                                 o_err.data_ptr(), lk)
-        for _ in range(2):
-            full_step()
-        ctx.sync()
-        t = time.perf_counter()
-        for _ in range(reps):
-            full_step()
-        ctx.sync()
-        t_full = (time.perf_counter() - t) / reps
+
+        def timed_full(side_by_side, upload=None):
+            for _ in range(3):
+                if upload is not None:
+                    ctx.upload_images(slots, upload)
+                full_step(side_by_side)
+            ctx.sync()
+            t = time.perf_counter()
+            for _ in range(reps):
+                if upload is not None:
+                    ctx.upload_images(slots, upload)
+                full_step(side_by_side)
+            ctx.sync()
+            return (time.perf_counter() - t) / reps
+
+        reps = max(5, a.steps // 2)
+        t_full = timed_full(False)
         real = torch.arange(NF, device=dev)[None, :] < d_cc[:, None].to(torch.int64)
         tracked_full = int((o_status.bool() & real).sum().item())
+        ref_bits = (o_next.clone(), o_status.clone())
+        t_side = timed_full(True)
+        assert torch.equal(o_next, ref_bits[0]) and torch.equal(o_status, ref_bits[1]), "side-by-side step differs"
+        # ... and fed from the host: the step's frames uploaded from pinned memory every step (one DMA on the copy
+        # stream under the previous step's kernels, one ingest launch), then detected, built and tracked: the whole
+        # configs[1] stream as one number
+        stream_full = None
+        if not a.skip_stream:
+            host_f = torch.from_numpy(np.stack(frames)).pin_memory()
+            t_sf = timed_full(True, host_f.numpy())
+            assert torch.equal(o_next, ref_bits[0]) and torch.equal(o_status, ref_bits[1]), "host-fed step differs"
+            stream_full = {"ms_per_step": t_sf * 1e3, "value": tracked_full / t_sf, "unit": "tracked features/s",
+                           "tracked_per_step": tracked_full,
+                           "note": "per step: ktlvo_upload_images (all %d frames, %.1f MB, one DMA from pinned memory on the copy "
+                                   "stream + one ingest launch), ktlvo_detect_build_frames_dev (corners of the %d first frames and "
+                                   "all pyramids, side by side), ktlvo_pyrlk_batch_dev on the detected corners; one context "
+                                   "running ahead of the device, every step's results identical to the resident step's"
+                                   % (NI, NI * W * H / 1e6, NP)}
+            del host_f
+        del ref_bits
+        # the detector's three kernels on their own (events around each launch of the batch)
+        cand_px = NP * W * H
+        detect = {"ms_per_step": t_det * 1e3, "frames": NP, "corners": int(cc.sum()), "us_per_frame": t_det / NP * 1e6,
+                  "algorithmic_bytes": cand_px + 12 * int(cc.sum()),
+                  "achieved_GBps": (cand_px + 12 * int(cc.sum())) / t_det / 1e9,
+                  "detect_build_track": {"ms_per_step": t_full * 1e3, "tracked_per_step": tracked_full,
+                                         "value": tracked_full / t_full, "unit": "tracked features/s",
+                                         "arrangement": "ktlvo_detect_gftt_frames_dev, ktlvo_build_pyramids, ktlvo_pyrlk_batch_dev in turn"},
+                  "detect_build_track_side_by_side": {"ms_per_step": t_side * 1e3, "tracked_per_step": tracked_full,
+                                                      "value": tracked_full / t_side, "unit": "tracked features/s",
+                                                      "arrangement": "ktlvo_detect_build_frames_dev (pyramid build on a side stream "
+                                                                     "beside the detection), ktlvo_pyrlk_batch_dev"},
+                  "stream_full": stream_full,
+                  "note": "ktlvo_detect_gftt_frames_dev: Shi-Tomasi corners (quality 0.01, minDistance %g, at most %d) of the "
+                          "step's %d first frames in one call, output on the device; algorithmic bytes = W H per frame read + "
+                          "12 B per corner written" % (a.min_dist, NF, NP)}
         step()                                   # the resident-input step's outputs back in place
         ctx.sync()
-        detect = {"ms_per_step": t_det * 1e3, "frames": NP, "corners": int(cc.sum()), "us_per_frame": t_det / NP * 1e6,
-                  "detect_build_track": {"ms_per_step": t_full * 1e3, "tracked_per_step": tracked_full,
-                                         "value": tracked_full / t_full, "unit": "tracked features/s"},
-                  "note": "ktlvo_detect_gftt_frames_dev: Shi-Tomasi corners (quality 0.01, minDistance %g, at most %d) of the "
-                          "step's %d first frames in one call, output on the device; one frame per call costs %s" % (
-                              a.min_dist, NF, NP, "0.14 ms at this size" if (W, H) == (1241, 376) else "more")}
         del d_cxy, d_cr, d_cc
 
     # ---- the same step fed from host memory every time (frame-pair STREAM, never the headline) ------------

@@ -187,6 +187,15 @@ int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, con
  * than 512K pixels before that for the candidate counts that size its lists.) */
 int ktlvo_detect_gftt_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi,
                                  const ktlvo_gftt_params *params, float *d_xy, float *d_response, int *d_counts, int cap);
+/* Corners of one batch of slots and pyramids of another (usually overlapping) batch in one call: what a frame-pair
+ * stream does with every batch of new frames (featureTracking.cpp:408-430 detects on the new key frame;
+ * calcOpticalFlowPyrLK, :457-479, builds the pyramids it tracks on).  The two are independent and load the GPU in
+ * complementary ways, so the build (ktlvo_build_pyramids of build_slots) runs on a side stream BESIDE the detection
+ * (ktlvo_detect_gftt_frames_dev of detect_slots) and the context's stream waits for both: results are those of the two
+ * calls made one after the other, a following ktlvo_pyrlk_batch_dev finds corners and pyramids complete. */
+int ktlvo_detect_build_frames_dev(ktlvo_ctx *ctx, const int *detect_slots, int n_frames, const ktlvo_roi *roi,
+                                  const ktlvo_gftt_params *params, float *d_xy, float *d_response, int *d_counts,
+                                  int cap, const int *build_slots, int n_build, int max_level, int win);
 /* The same detection for callers that must not allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc,
  * hipFree or other allocating routine, copies nothing and does not synchronise: the ROI list travels as

@@ -35,6 +35,8 @@
 // seen, is applied to the sorted keys.  An ROI whose maximum is not positive has no corners (for
 // quality <= 1 nothing exceeds quality * max then), and none are emitted.
 #include "ctx.hpp"
+
+#include <functional>
 #include "internal.hpp"
 
 #include <cstring>
@@ -82,6 +84,26 @@ __global__ void corner_setup(RoiTable t, int n_roi, RoiDev *rois, unsigned *roi_
         cand_cnt[i] = 0;
     }
     if (i == 0) { overflow[0] = 0; overflow[1] = 0; } // [1]: a blind route asks for the call to be done again the other way
+}
+
+// The same for a batch of frames that share one region: frame f's table entry is the region at candidate offset
+// f * area, and its slot number goes into the list the candidates kernel reads.  One launch instead of two copies from
+// host memory and three memsets (some 25 us of stream time in front of the batch's first kernel).
+struct FrameSlots {
+    int s[MAX_BATCH];
+};
+__global__ void corner_setup_frames(FrameSlots t, int n_frames, RoiDev region, RoiDev *rois, int *roi_slots, unsigned *roi_max,
+                                    int *cand_cnt, int *overflow) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_frames) {
+        RoiDev r = region;
+        r.off = region.off * i; // region.off holds the area
+        rois[i] = r;
+        roi_slots[i] = t.s[i];
+        roi_max[i] = 0u;
+        cand_cnt[i] = 0;
+    }
+    if (i == 0) { overflow[0] = 0; overflow[1] = 0; }
 }
 
 __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, int slot, const RoiDev *rois, float s1,
@@ -2182,12 +2204,12 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
 // one workgroup, its sort a few dozen); a batch fills it, and the cost per frame drops by two orders of magnitude.
 // Per frame the result is ktlvo_detect_gftt's for that slot and ROI (same candidates, same unique keys in the same
 // order, same greedy pass).  Outputs are device arrays [n_frames][cap]; the call returns once they are complete.
+// before_candidates, if given, is called right before the candidates launch is queued on the context's stream, once the
+// work area is set up (the detect-and-build entry point queues the pyramid build on the side stream there).
 static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi &roi, const ktlvo_gftt_params *p,
-                             float *d_xy, float *d_resp, int *d_counts, int cap) {
+                             float *d_xy, float *d_resp, int *d_counts, int cap, const std::function<int()> &before_candidates = nullptr) {
     const size_t area = (size_t)roi.w * roi.h;
     if (area * (size_t)n_frames > 0x7fffffff) return KTLVO_ERR_CAPACITY; // candidate offsets are 32-bit
-    std::vector<RoiDev> rois(n_frames);
-    for (int f = 0; f < n_frames; f++) rois[f] = {roi.x, roi.y, roi.w, roi.h, (int)(area * f)};
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     // work area: the detector's scratch for n_frames ROIs, then the frames' slot numbers, then their candidate counts' pinned mirror
     const size_t o_slots = up(corner_scratch_bytes(n_frames, area * n_frames));
@@ -2198,11 +2220,18 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
     CornerScratch s;
     corner_scratch_carve(ctx->d_misc, n_frames, area * n_frames, s);
     int *d_roi_slots = (int *)((char *)ctx->d_misc + o_slots);
-    int *h_slots = (int *)ctx->h_pin, *h_cnt = h_slots + n_frames, *h_ovf = h_cnt + n_frames, *h_many = h_ovf + 1;
-    for (int f = 0; f < n_frames; f++) h_slots[f] = slots[f];
-    KTLVO_HIP(ctx, hipMemcpyAsync(d_roi_slots, h_slots, 4 * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
-    rc = corner_scratch_setup(ctx, rois.data(), n_frames, s);
-    if (rc != KTLVO_OK) return rc;
+    int *h_cnt = (int *)ctx->h_pin + n_frames, *h_ovf = h_cnt + n_frames, *h_many = h_ovf + 1;
+    {
+        FrameSlots t;
+        for (int f = 0; f < n_frames; f++) t.s[f] = slots[f];
+        hipLaunchKernelGGL(corner_setup_frames, dim3((n_frames + 255) / 256), dim3(256), 0, ctx->stream, t, n_frames,
+                           RoiDev{roi.x, roi.y, roi.w, roi.h, (int)area}, s.d_rois, d_roi_slots, s.d_max, s.d_cnt, s.d_overflow);
+        KTLVO_HIP(ctx, hipGetLastError());
+    }
+    if (before_candidates) {
+        rc = before_candidates();
+        if (rc != KTLVO_OK) return rc;
+    }
     rc = run_candidates(ctx, -1, n_frames, roi.w, roi.h, p->use_harris, p->harris_k, s, nullptr, true, d_roi_slots, true, roi.w, roi.h);
     if (rc != KTLVO_OK) return rc;
     const bool dist = p->min_dist >= 1;
@@ -2353,8 +2382,17 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (!*h_many) return KTLVO_OK;
     }
-    // the overflow flag lands in pinned memory behind the counts' mirror; a caller that waits for the stream reads it there
+    // the overflow flag lands in pinned memory behind the counts' mirror; every return of this function finds it there
     KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KTLVO_OK;
+}
+
+// After detect_frames_dev: a cell of the minimum-distance grid that ran out of places (more than four accepted corners
+// in one cell, which the distance rule excludes for cells of the rule's own size) would have dropped a corner.
+static int frames_overflow_check(ktlvo_ctx *ctx, int n_frames) {
+    const int *h_ovf = (const int *)ctx->h_pin + 2 * n_frames;
+    if (*h_ovf) { ctx->last_error = "corner selection: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
     return KTLVO_OK;
 }
 
@@ -2444,7 +2482,59 @@ extern "C" int ktlvo_detect_gftt_frames_dev(ktlvo_ctx *ctx, const int *slots, in
     int rc = frames_args_ok(ctx, slots, n_frames, roi_in, p, cap, roi);
     if (rc != KTLVO_OK) return rc;
     ProfScope ps(ctx, KTLVO_K_CORNER);
-    return detect_frames_dev(ctx, slots, n_frames, roi, p, d_xy, d_response, d_counts, cap);
+    rc = detect_frames_dev(ctx, slots, n_frames, roi, p, d_xy, d_response, d_counts, cap);
+    return rc != KTLVO_OK ? rc : frames_overflow_check(ctx, n_frames);
+}
+
+// Detection and pyramid build of a batch side by side.  The two share nothing but their input (the detector reads
+// the level-0 image planes, the build reads them and writes the other levels and the derivative planes), and they load
+// the chip in complementary ways: the detector's first kernel (candidates) is bound by instruction issue, its sort and
+// greedy pass are a workgroup per frame and leave most of the chip idle, the pyramid kernels are bound by memory
+// traffic.  The build is queued on the device's side stream behind a fence on the context's stream, the detection on
+// the context's stream, and the context's stream then waits for the build, so whatever the caller queues next
+// (ktlvo_pyrlk_batch_dev) finds corners and pyramids complete.  Measured on the benchmark's 254 + 256 frames, same box:
+// 0.87 ms for the two calls in turn, 0.69 ms side by side (the build queued beside the candidates launch; queued
+// behind it, beside the sort and the greedy pass only, 0.73 ms: the pyramid kernels then end after the greedy pass).
+extern "C" int ktlvo_detect_build_frames_dev(ktlvo_ctx *ctx, const int *detect_slots, int n_frames, const ktlvo_roi *roi_in,
+                                             const ktlvo_gftt_params *p, float *d_xy, float *d_response, int *d_counts,
+                                             int cap, const int *build_slots, int n_build, int max_level, int win) {
+    if (!ctx || !p || n_frames < 0 || (n_frames > 0 && !detect_slots) || n_build < 0 || (n_build > 0 && !build_slots))
+        return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (n_build == 0) return ktlvo_detect_gftt_frames_dev(ctx, detect_slots, n_frames, roi_in, p, d_xy, d_response, d_counts, cap);
+    if (n_frames == 0) return ktlvo_build_pyramids(ctx, build_slots, n_build, max_level, win);
+    if (!d_xy || !d_response || !d_counts) return KTLVO_ERR_INVALID;
+    ktlvo_roi roi; // refuse bad arguments of either half before anything is queued
+    int rc = frames_args_ok(ctx, detect_slots, n_frames, roi_in, p, cap, roi);
+    if (rc != KTLVO_OK) return rc;
+    if (max_level < 0) return KTLVO_ERR_INVALID;
+    if (win != ctx->cfg.win) return KTLVO_ERR_UNSUPPORTED;
+    for (int i = 0; i < n_build; i++) {
+        if (!slot_ok(ctx, build_slots[i])) return KTLVO_ERR_INVALID;
+        if (ctx->built[build_slots[i]] < 0) return KTLVO_ERR_STATE;
+    }
+    rc = device_streams(ctx);
+    if (rc != KTLVO_OK) return rc;
+    hipStream_t const main_stream = ctx->stream;
+    bool forked = false;
+    auto build_on_side_stream = [&]() -> int {
+        KTLVO_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        KTLVO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->side_stream; // the build's launches (and its profiling events) go to the side stream
+        const int rb = ktlvo_build_pyramids(ctx, build_slots, n_build, max_level, win);
+        ctx->stream = main_stream;
+        if (rb != KTLVO_OK) return rb;
+        KTLVO_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+        forked = true;
+        return KTLVO_OK;
+    };
+    {
+        ProfScope ps(ctx, KTLVO_K_CORNER);
+        rc = detect_frames_dev(ctx, detect_slots, n_frames, roi, p, d_xy, d_response, d_counts, cap, build_on_side_stream);
+    }
+    // (also after a failed detection: the planes are being written)
+    if (forked) KTLVO_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+    return rc != KTLVO_OK ? rc : frames_overflow_check(ctx, n_frames);
 }
 
 extern "C" int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi_in,
@@ -2474,9 +2564,7 @@ extern "C" int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_
     KTLVO_HIP(ctx, hipMemcpyAsync(response, d_resp, b_r, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipMemcpyAsync(counts, d_counts, b_c, hipMemcpyDeviceToHost, ctx->stream));
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int *h_ovf = (const int *)ctx->h_pin + 2 * n_frames;
-    if (*h_ovf) { ctx->last_error = "corner selection: cell capacity exceeded"; return KTLVO_ERR_UNSUPPORTED; }
-    return KTLVO_OK;
+    return frames_overflow_check(ctx, n_frames);
 }
 
 extern "C" int ktlvo_corner_response(ktlvo_ctx *ctx, int slot, const ktlvo_roi *roi, int use_harris, double harris_k,

@@ -1,6 +1,8 @@
 // Context life cycle, stream handling, profiling events and error strings of libktlvo_hip.so.
 #include "ctx.hpp"
 
+#include <mutex>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -80,6 +82,53 @@ int effective_max_level(const ktlvo_ctx *ctx, int a, int b, int requested) {
 } // namespace ktlvo
 
 using namespace ktlvo;
+
+namespace ktlvo {
+// One copy stream and one side stream per device for the whole process, counted by the contexts that hold them and
+// destroyed with the last one.  A context per host thread is this library's threading model, and a stream-feeding
+// harness runs several; with three streams of its own per context, a handful of contexts outgrows the process's
+// hardware queues (GPU_MAX_HW_QUEUES, 4 by default).  Streams that share a hardware queue execute in the order they
+// were submitted to it, so a hipStreamWaitEvent packet of one stream can sit in that queue AHEAD of the kernel of
+// another stream that is to signal the event, and neither moves.  Sharing keeps a process at (contexts + 2) streams
+// per device instead of 3 x contexts; the streams themselves are thread-safe.
+struct DeviceStreams {
+    hipStream_t copy = nullptr, side = nullptr;
+    int users = 0;
+};
+static std::mutex g_streams_mutex;
+static DeviceStreams g_streams[64];
+
+int device_streams(ktlvo_ctx *ctx) {
+    if (ctx->holds_device_streams) return KTLVO_OK;
+    if (ctx->device < 0 || ctx->device >= 64) return KTLVO_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    DeviceStreams &d = g_streams[ctx->device];
+    if (!d.copy) KTLVO_HIP(ctx, hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking));
+    if (!d.side) KTLVO_HIP(ctx, hipStreamCreateWithFlags(&d.side, hipStreamNonBlocking));
+    if (!ctx->ev_fork) KTLVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) KTLVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    d.users++;
+    ctx->copy_stream = d.copy;
+    ctx->side_stream = d.side;
+    ctx->holds_device_streams = true;
+    return KTLVO_OK;
+}
+
+static void release_device_streams(ktlvo_ctx *ctx) {
+    if (!ctx->holds_device_streams) return;
+    std::lock_guard<std::mutex> lock(g_streams_mutex);
+    DeviceStreams &d = g_streams[ctx->device];
+    (void)hipStreamSynchronize(d.copy);
+    (void)hipStreamSynchronize(d.side);
+    if (--d.users == 0) {
+        (void)hipStreamDestroy(d.copy);
+        (void)hipStreamDestroy(d.side);
+        d.copy = d.side = nullptr;
+    }
+    ctx->copy_stream = ctx->side_stream = nullptr;
+    ctx->holds_device_streams = false;
+}
+} // namespace ktlvo
 
 extern "C" int ktlvo_default_config(ktlvo_config *c) {
     if (!c) return KTLVO_ERR_INVALID;
@@ -210,13 +259,16 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
         if (ctx->stage.done[i]) (void)hipEventDestroy(ctx->stage.done[i]);
     }
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     for (int k = 0; k < 2; k++) {
         if (ctx->stage.d_batch[k]) (void)hipFree(ctx->stage.d_batch[k]);
         if (ctx->stage.h_batch[k]) (void)hipHostFree(ctx->stage.h_batch[k]);
         if (ctx->stage.batch_done[k]) (void)hipEventDestroy(ctx->stage.batch_done[k]);
         if (ctx->stage.copy_done[k]) (void)hipEventDestroy(ctx->stage.copy_done[k]);
     }
-    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    release_device_streams(ctx);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (int i = 0; i < 4; i++) if (ctx->d_pts[i]) (void)hipFree(ctx->d_pts[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_err) (void)hipFree(ctx->d_err);

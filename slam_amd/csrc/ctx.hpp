@@ -75,7 +75,13 @@ struct ktlvo_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr; // stream in use (own_stream or the caller's)
-    hipStream_t copy_stream = nullptr; // host-to-device DMA of ktlvo_upload_images (made on first use)
+    // The process keeps ONE copy stream and ONE side stream per device, shared by all its contexts on that device
+    // (ctx.hip, device_streams): a process has few hardware queues (4 by default), and streams beyond them share
+    // queues, where a wait packet can sit in front of the very work it waits for.  Both are taken on first use.
+    hipStream_t copy_stream = nullptr; // host-to-device DMA of ktlvo_upload_images
+    hipStream_t side_stream = nullptr; // the pyramid build of ktlvo_detect_build_frames_dev, beside the detection
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // this context's fences between its stream and the side stream
+    bool holds_device_streams = false;
     std::string last_error;
 
     // image slots
@@ -142,6 +148,7 @@ struct ProfScope {
     ~ProfScope();
 };
 
+int device_streams(ktlvo_ctx *ctx); // ctx.hip: fills ctx->copy_stream and ctx->side_stream (shared per device)
 int corner_noalloc_init(ktlvo_ctx *ctx); // corners.hip
 int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const uint8_t *b, int w, int h); // pyramid.hip
 int ensure_misc(ktlvo_ctx *ctx, size_t bytes);

@@ -462,7 +462,10 @@ extern "C" int ktlvo_upload_images(ktlvo_ctx *ctx, const int *slots, int n, cons
         if (!slot_ok(ctx, slots[i])) return KTLVO_ERR_INVALID;
     const size_t bytes = image_stride * (size_t)(n - 1) + (size_t)stride * (h - 1) + w;
     StageRing &r = ctx->stage;
-    if (!ctx->copy_stream) KTLVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    {
+        const int rc_s = device_streams(ctx);
+        if (rc_s != KTLVO_OK) return rc_s;
+    }
     const bool pinned = is_pinned(imgs);
     const int k = r.batch_next;
     int rc = stage_take(ctx, bytes, k, !pinned);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ktlvo_detect_gftt": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_detect_gftt_frames": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_detect_gftt_frames_dev": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
+    "ktlvo_detect_build_frames_dev": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i, _ip, _i, _i, _i]),
     "ktlvo_detect_gftt_noalloc": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_corner_response": (_i, [_vp, _i, C.POINTER(Roi), _i, _d, _vp]),
     "ktlvo_anms": (_i, [_vp, _vp, _vp, _ip, _i]),
@@ -362,6 +363,17 @@ class Context:
         r = C.byref(Roi(*roi)) if roi is not None else None
         self._chk(lib.ktlvo_detect_gftt_frames_dev(self._h, arr, n, r, C.byref(params), d_xy, d_resp, d_counts, cap),
                   "ktlvo_detect_gftt_frames_dev")
+
+    def detect_build_frames_dev(self, detect_slots, params, d_xy, d_resp, d_counts, cap, build_slots, roi=None,
+                                max_level=None, win=None):
+        """Corners of detect_slots and pyramids of build_slots side by side (device outputs as detect_gftt_frames_dev)."""
+        n, nb = len(detect_slots), len(build_slots)
+        arr = (C.c_int * max(n, 1))(*detect_slots)
+        barr = (C.c_int * max(nb, 1))(*build_slots)
+        r = C.byref(Roi(*roi)) if roi is not None else None
+        self._chk(lib.ktlvo_detect_build_frames_dev(self._h, arr, n, r, C.byref(params), d_xy, d_resp, d_counts, cap, barr, nb,
+                                                    self.cfg.max_level if max_level is None else max_level,
+                                                    self.cfg.win if win is None else win), "ktlvo_detect_build_frames_dev")
 
     def detect_gftt_noalloc(self, slot, rois, params, d_xy, d_resp, d_counts, cap):
         """Device-pointer form that allocates nothing; returns the status code (no exception) so that tests

@@ -790,6 +790,76 @@ def test_large_batch_small_levels_equal_per_level_launches(make_ctx, oracle, siz
         assert all(np.array_equal(p, q) for p, q in zip(ra, rb)), (a_, b_)
 
 
+def test_detect_and_build_side_by_side_equals_calls_in_turn(make_ctx, klib):
+    """ktlvo_detect_build_frames_dev (pyramid build on a side stream beside the detection) against
+    ktlvo_detect_gftt_frames_dev followed by ktlvo_build_pyramids: same corners, same planes at every level, and the
+    tracks a following ktlvo_pyrlk_batch_dev makes of them are the same bits; twice in a row with new frames in the
+    same slots (the second round's ingest, build and detection must wait for the first round's tracks), with pinned
+    frames uploaded in bulk; plus the empty halves and the refusals, which queue nothing."""
+    import torch
+    W, H, n = 640, 360, 6
+    a, b = make_ctx(width=W, height=H, num_slots=n), make_ctx(width=W, height=H, num_slots=n)
+    params = klib.gftt_params(600, 0.01, 7.0, 3, 0, 0.0)
+    lk = klib.lk_params()
+    prev, nxt = [0, 1, 2, 3, 4], [1, 2, 3, 4, 5]
+    out = {}
+    for tag, ctx in (("turn", a), ("side", b)):
+        d_xy = torch.zeros((5, 600, 2), device="cuda")
+        d_r = torch.zeros((5, 600), device="cuda")
+        d_c = torch.zeros(5, dtype=torch.int32, device="cuda")
+        d_n = torch.zeros((5, 600, 2), device="cuda")
+        d_s = torch.zeros((5, 600), dtype=torch.uint8, device="cuda")
+        d_e = torch.zeros((5, 600), device="cuda")
+        torch.cuda.synchronize()
+        res = []
+        for rnd in range(2):
+            imgs = np.stack([synth.texture_image(W, H, 50 + 10 * rnd, dx=0.8 * s, dy=-0.3 * s, noise=True) for s in range(n)])
+            pinned = torch.from_numpy(imgs).pin_memory()
+            ctx.upload_images(list(range(n)), pinned.numpy())
+            if tag == "turn":
+                ctx.detect_gftt_frames_dev(prev, params, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), 600)
+                ctx.build_pyramids(list(range(n)))
+            else:
+                ctx.detect_build_frames_dev(prev, params, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), 600, list(range(n)))
+            ctx.pyrlk_batch_dev(prev, nxt, d_xy.data_ptr(), 600, d_n.data_ptr(), d_s.data_ptr(), d_e.data_ptr(), lk)
+            ctx.sync()
+            planes = [(ctx.download_level(s_, l), ctx.download_scharr(s_, l, *ctx.download_level(s_, l).shape[::-1]))
+                      for s_ in (0, n - 1) for l in range(ctx.pyramid_levels(s_) + 1)]
+            res.append((d_xy.cpu().numpy().copy(), d_r.cpu().numpy().copy(), d_c.cpu().numpy().copy(), d_n.cpu().numpy().copy(),
+                        d_s.cpu().numpy().copy(), d_e.cpu().numpy().copy(), planes))
+        out[tag] = res
+    for rnd in range(2):
+        t, s_ = out["turn"][rnd], out["side"][rnd]
+        cnt = t[2]
+        assert np.array_equal(cnt, s_[2]) and cnt.min() > 100
+        for f in range(5):
+            k = int(cnt[f])
+            assert np.array_equal(t[0][f, :k], s_[0][f, :k]) and np.array_equal(t[1][f, :k], s_[1][f, :k])
+            assert np.array_equal(t[3][f, :k], s_[3][f, :k]) and np.array_equal(t[4][f, :k], s_[4][f, :k])
+            assert np.array_equal(t[5][f, :k], s_[5][f, :k])
+        for (la, da), (lb, db) in zip(t[6], s_[6]):
+            assert np.array_equal(la, lb) and np.array_equal(da, db)
+    assert not np.array_equal(out["turn"][0][3], out["turn"][1][3])          # the rounds really differ
+    # empty halves
+    d_xy = torch.zeros((2, 600, 2), device="cuda"); d_r = torch.zeros((2, 600), device="cuda")
+    d_c = torch.zeros(2, dtype=torch.int32, device="cuda")
+    b.detect_build_frames_dev([], params, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), 600, [0, 1])   # build only
+    b.detect_build_frames_dev([0, 1], params, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), 600, [])   # detect only
+    b.sync()
+    assert np.array_equal(d_c.cpu().numpy(), out["side"][1][2][:2])
+    # refusals: a slot without an image in either list, a window the context was not sized for
+    c = make_ctx(width=W, height=H, num_slots=3)
+    c.upload_image(0, synth.texture_image(W, H, 3))
+    for det, bld in (([0], [0, 1]), ([1], [0])):
+        with pytest.raises(klib.KtlvoError) as ei:
+            c.detect_build_frames_dev(det, params, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), 600, bld)
+        assert ei.value.status == klib.ERR_STATE
+    with pytest.raises(klib.KtlvoError) as ei:
+        c.detect_build_frames_dev([0], params, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), 600, [0], win=15)
+    assert ei.value.status == klib.ERR_UNSUPPORTED
+    assert c.pyramid_levels(0) == 0                                           # nothing was built by the refused calls
+
+
 def test_batched_detection_equals_per_frame_detection(make_ctx, klib):
     """ktlvo_detect_gftt_frames: the whole-frame detector over a batch of frames with the launches of one
     detection.  Every frame's corners, order and responses equal ktlvo_detect_gftt's for that frame: frames of
