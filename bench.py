@@ -37,6 +37,11 @@ HBM_COPY_GBS = 6290.0          # measured float4-copy ceiling
 WIN = 21
 
 
+# the arithmetic the path computes in, by the reading of LK's window sums (ktlvo_lk_params.sums)
+DTYPE = {0: "u8 -> i32 fixed point, exact i64-equivalent window sums rounded once to f32",
+         2: "u8 -> i32 fixed point, exact i64-equivalent window sums rounded once to f32",
+         1: "u8 -> i32 fixed point, f32 window sums in a fixed 64-lane tree"}
+
 PREWARM_STEPS = 40  # untimed steps before the warm-up proper (clock run-up after the host-side set-up)
 
 
@@ -154,6 +159,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="sequence workload: tracker instances per GPU, one host thread and one HIP stream each")
     a = ap.parse_args()
+    # the sequence workload runs the reference's own frame unless told otherwise
+    a.seq_width, a.seq_height = a.width or 1242, a.height or 375
     # shapes left open take the workload's BASELINE shape: configs[4] for the fixed batch, configs[1] otherwise
     shape = (3840, 2160, 16384, 8.0) if a.workload == "batch" else (1241, 376, 2000, 10.0)
     if a.width is None: a.width = shape[0]
@@ -165,16 +172,17 @@ def parse():
 
 
 def run_sequence(a, rank, world, local, dev):
-    """Stereo tracker + RANSAC pose on one synthetic 1242x375 corridor sequence per rank; every rank
-    runs its own sequence (seed + rank) and the 4x4 poses are gathered with one all_gather."""
-    W, H = 1242, 375
+    """Stereo tracker + RANSAC pose on one synthetic corridor sequence per rank (the reference's 1242x375 frame,
+    cameraParameters.h:16-17, unless --width/--height say otherwise: BASELINE configs[0] and [3] name 1241x376);
+    every rank runs its own sequence (seed + rank) and the 4x4 poses are gathered with one all_gather."""
+    W, H = a.seq_width, a.seq_height
     scene = synth.CorridorScene(W, H, seed=shard.rank_seed(0x5EED0010, rank + a.rank_offset))
     frames = [scene.stereo_pair(f) for f in range(a.frames)]
     # --streams S: S tracker instances (contexts, each with its own HIP stream) driven by S host threads
     # on this rank's GPU, all fed the same sequence; a single instance is latency-bound and leaves most
     # of the GPU idle.  Instance 0 provides the trajectory; the others must reproduce it bit for bit.
     S = max(1, a.streams)
-    ctxs = [K.Context(K.default_config(width=W, height=H), device=local) for _ in range(S)]
+    ctxs = [K.Context(K.default_config(width=W, height=H, cx=scene.cx, cy=scene.cy), device=local) for _ in range(S)]
     all_poses = [np.zeros((a.frames, 16), np.float32) for _ in range(S)]
     stats = [None] * S
 
@@ -227,7 +235,7 @@ def run_sequence(a, rank, world, local, dev):
         np.save(a.dump_trajectories, np.asarray(traj))   # [world, frames, 16], for the sharding parity test
     if rank == 0:
         print(json.dumps({
-            "metric": "stereo frames/sec, ktl_vo frontend + RANSAC pose (1242x375, reference parameters)",
+            "metric": "stereo frames/sec, ktl_vo frontend + RANSAC pose (%dx%d, reference parameters)" % (W, H),
             "value": float(recs[:, 0].sum()) * S / t_max, "unit": "frames/s", "n_gpus": world, "scaling": "weak",
             "data": "synthetic", "frames_per_rank": a.frames * S, "tracker_instances_per_gpu": S,
             "ms_per_frame": t_max / a.frames * 1e3,
@@ -235,7 +243,8 @@ def run_sequence(a, rank, world, local, dev):
                           "elapsed_s": r[5]} for r in recs.tolist()],
             "trajectory_shape": list(traj.shape),
             "note": "per frame: 2 host->device uploads (pinned staging), 1 pyramid + Scharr build for the two new "
-                    "images, 3 LK launches (the reference's 8 calls) with device-side gating, RANSAC pose with one scoring launch"}))
+                    "images, ONE LK launch for the reference's 8 calls (six tracks per point as two chains), one gate kernel, "
+                    "RANSAC pose with one scoring launch"}))
     for c in ctxs:
         c.close()
 
@@ -386,10 +395,11 @@ def run_batch(a, rank, world, local, dev):
         bpf = lk_bytes_per_feature(levels)
         k3_avg_s = max(float(r[3]) / max(float(r[4]), 1.0) for r in recs.tolist()) * 1e-3   # slowest rank's launch
         print(json.dumps({
-            "metric": "tracked features/sec @1241x376, 4-lvl 21x21 PyrLK, 1-8 GPU; % of HBM peak",
+            "metric": "tracked features/sec @%dx%d, 4-lvl 21x21 PyrLK, fixed batch of %d frame pairs sharded over 1-8 GPU; "
+                      "%% of HBM peak" % (W, H, NB),
             "value": tracked * a.steps / t_max, "unit": "tracked features/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": t_max / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u8 -> i32 fixed point, f32 sums", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[a.lk_sums], "data": "synthetic",
             "config": {"workload": "%sfixed batch of %d independent %dx%d frame pairs, %d Shi-Tomasi corners each, sharded "
                                    "round-robin by pair index; maxLevel=%d, 21x21 window, 30 it / eps 0.01" % (
                                        "BASELINE configs[4]: " if (W, H, NF, NB) == (3840, 2160, 16384, 64) else "",
@@ -410,10 +420,12 @@ def run_batch(a, rank, world, local, dev):
 
 
 def cpu_baseline(frames, pts, max_level, budget_s):
-    """The oracle (a port of the OpenCV path the reference calls) timed on the host cores: per
-    pair both pyramids, the previous image's Scharr planes and the LK loop, as one
-    cv::calcOpticalFlowPyrLK call does.  Bounded sample: the first pairs of the same workload,
-    repeated until the time budget is spent."""
+    """The oracle (a port of the OpenCV path the reference calls) timed on the host cores: per pair both pyramids, the
+    previous image's Scharr planes and the LK loop, as one cv::calcOpticalFlowPyrLK call does, every stage cut over
+    the threads of a persistent pool as cv::parallel_for_ does it (the reference never calls cv::setNumThreads, so
+    all cores is its configuration).  Bounded sample: the first pairs of the same workload, repeated until the time
+    budget is spent.  Timed with the serial float accumulator of OpenCV's scalar path (`value`) and with four
+    accumulators, as an SSE2 build of OpenCV sums; and on one thread."""
     import oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -421,22 +433,23 @@ def cpu_baseline(frames, pts, max_level, budget_s):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores))))
     n_pairs = min(len(frames) - 1, 4)
+    base = O.Baseline()
 
-    def timed(threads, budget):
+    def timed(threads, budget, sums):
         tracked, t0, reps = 0, time.perf_counter(), 0
         while True:
             for i in range(n_pairs):
-                pa = O.Pyramid(frames[i], max_level, WIN, True)
-                pb = O.Pyramid(frames[i + 1], max_level, WIN, False)
-                _, st, _ = O.pyrlk(pa, pb, pts[i], WIN, max_level, nthreads=threads)
+                _, st, _ = base.track_pair(frames[i], frames[i + 1], pts[i], max_level, WIN, threads, sums)
                 tracked += int(st.sum())
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget or reps >= 1000:
                 return tracked / el, reps, el
 
-    v_all, reps, el = timed(cores, budget_s)
-    v_one, reps1, el1 = timed(1, max(1.0, budget_s * 0.3))
+    timed(cores, 0.5, O.SUMS_SERIAL)                      # pool start-up and page faults of the first calls
+    v_all, reps, el = timed(cores, budget_s * 0.5, O.SUMS_SERIAL)
+    v_four, reps4, el4 = timed(cores, budget_s * 0.25, O.SUMS_FOUR_LANES)
+    v_one, reps1, el1 = timed(1, max(1.0, budget_s * 0.25), O.SUMS_SERIAL)
     # Gauss-Newton steps per level of the first pair (levels listed from level 0 up)
     it, _ = O.lk_iterations(O.Pyramid(frames[0], max_level, WIN, True), O.Pyramid(frames[1], max_level, WIN, False),
                             pts[0], max_level=max_level)
@@ -450,9 +463,14 @@ def cpu_baseline(frames, pts, max_level, budget_s):
         pass
     return {"value": v_all, "unit": "tracked features/s", "cores": cores, "kind": "port",
             "sample": "first %d frame pairs x %d features of the same workload, %d repetitions, %.1f s; "
-                      "pyramids + Scharr + LK per pair (one calcOpticalFlowPyrLK each), points range-split "
-                      "over %d threads" % (n_pairs, pts.shape[1], reps, el, cores),
+                      "pyramids + Scharr + LK per pair (one calcOpticalFlowPyrLK each), image rows and point stripes "
+                      "taken by %d pooled threads; serial float accumulators (OpenCV's scalar path)"
+                      % (n_pairs, pts.shape[1], reps, el, cores),
+            "four_accumulators": {"value": v_four, "cores": cores, "sample": "%d repetitions, %.1f s; window sums in four "
+                                  "float accumulators, as a 4-lane SIMD build of OpenCV adds them" % (reps4, el4)},
             "single_thread": {"value": v_one, "cores": 1, "sample": "%d repetitions, %.1f s" % (reps1, el1)},
+            "all_cores_over_one_thread": v_all / v_one if v_one > 0 else None,
+            "build": "g++ %s -ffp-contract=off" % base.build,
             "cpu_model": model,
             "lk_iterations_per_level_mean": [float(x) for x in it.mean(1)],
             "lk_iterations_per_feature_mean": float(it.sum(0).mean())}
@@ -796,6 +814,35 @@ def main():
         ml3 = {"value": tr3 * n3 / t3, "unit": "tracked features/s", "steps": n3, "tracked_per_step": tr3}
         ctx.build_pyramids(slots)   # leave the slots as the main run built them
         fence()
+    # the same step with the other reading of the window sums (float tree instead of exact totals, or the reverse)
+    other_sums = None
+    if world == 1 and not a.skip_secondary:
+        alt = K.LK_SUMS_EXACT if a.lk_sums == K.LK_SUMS_TREE else K.LK_SUMS_TREE
+        lk_alt = K.lk_params(WIN, a.max_level, sums=alt)
+        n_alt = max(5, a.steps // 2)
+
+        def step_alt():
+            ctx.build_pyramids(slots)
+            ctx.pyrlk_batch_dev(prev_slots, next_slots, d_prev.data_ptr(), NF, d_next.data_ptr(), d_status.data_ptr(),
+                                d_err.data_ptr(), lk_alt)
+        for _ in range(3):
+            step_alt()
+        fence()
+        ctx.profile_enable(2 << K.K_PYRLK)
+        ctx.profile_reset()
+        t_alt = time.perf_counter()
+        for _ in range(n_alt):
+            step_alt()
+        fence()
+        t_alt = time.perf_counter() - t_alt
+        ms_alt, nl_alt = ctx.profile_get(K.K_PYRLK)
+        ctx.profile_enable(False)
+        tr_alt = int(d_status.sum().item())
+        other_sums = {"sums": "exact" if alt == K.LK_SUMS_EXACT else "tree", "value": tr_alt * n_alt / t_alt,
+                      "unit": "tracked features/s", "steps": n_alt, "tracked_per_step": tr_alt,
+                      "ms_per_step": t_alt / n_alt * 1e3, "lk_launch_ms": ms_alt / max(nl_alt, 1)}
+        step()                                   # the main reading's outputs back in place
+        fence()
     soak = None
     if a.soak > 0:
         fence()
@@ -859,7 +906,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 -> i32 fixed point, f32 sums",
+            "dtype": DTYPE[a.lk_sums],
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if rehearsal else ""),
             "config": {
                 "workload": "%s%dx%d gray frame-pair stream, %d Shi-Tomasi corners/frame, "
@@ -869,6 +916,7 @@ def main():
                                 "BASELINE configs[4] shape: " if (W, H, NF) == (3840, 2160, 16384) else "",
                                 W, H, NF, a.max_level, levels),
                 "pairs_per_step": NP,
+                "lk_window_sums": "tree" if a.lk_sums == K.LK_SUMS_TREE else "exact",
                 "prewarm_steps": PREWARM_STEPS,
                 "sequences_per_step": Q,
                 "pipeline_contexts": len(ctxs),
@@ -929,6 +977,8 @@ def main():
             out["soak"] = soak
         if ml3 is not None:
             out["max_level_3"] = ml3
+        if other_sums is not None:
+            out["other_window_sums"] = other_sums
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(frames[:P + 1], pts[:P], a.max_level, a.cpu_seconds)
         print(json.dumps(out))

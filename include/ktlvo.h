@@ -204,7 +204,10 @@ int ktlvo_detect_build_frames_dev(ktlvo_ctx *ctx, const int *detect_slots, int n
  * d_response [n_roi][cap], d_counts [n_roi], valid once the context's stream has been waited for.
  * Limits: n_roi <= 192, ROI areas summing to <= 524288 pixels, every ROI <= 4096 pixels and <= 1024
  * min-distance cells (the reference's 59 x 39 sub-regions are 2301 pixels); beyond them the call returns
- * KTLVO_ERR_CAPACITY and enqueues nothing.  All calls on one GPU share the array: calls that overlap on
+ * KTLVO_ERR_CAPACITY and enqueues nothing.  Because the call never waits for the device it cannot report what only the
+ * kernels see: d_counts[roi] = -1 marks an ROI whose selection ran out of a kernel limit (more than four corners in one
+ * minimum-distance cell; the distance rule itself excludes that, and the sizes are checked before anything is queued,
+ * so no accepted call is known to produce it).  All calls on one GPU share the array: calls that overlap on
  * one GPU (two streams, two contexts, two processes' worth of threads) race; calls in stream order do
  * not, every call clears what it accumulates into. */
 int ktlvo_detect_gftt_noalloc(ktlvo_ctx *ctx, int slot, const ktlvo_roi *rois, int n_roi,

@@ -56,6 +56,8 @@ class Config(C.Structure):
     ]
 
 
+SUMS_SERIAL, SUMS_FOUR_LANES, SUMS_PAIRWISE, SUMS_EXACT = 0, 1, 2, 3   # orc_set_lk_sum_mode
+
 IMAGE_POINT = np.dtype([("u", "<f4"), ("v", "<f4"), ("ind", "<i4")])
 DEPTH_POINT = np.dtype([("u", "<f4"), ("v", "<f4"), ("depth", "<f4"), ("label", "<i4"), ("ind", "<i4"),
                         ("newKeyFrame", "<i4")])
@@ -96,6 +98,8 @@ _lib.orc_gao_quartic.restype = None
 _lib.orc_roots4.argtypes = [_f64p, _f64p]
 _lib.orc_set_lk_sum_mode.argtypes = [C.c_int]
 _lib.orc_set_lk_sum_mode.restype = None
+_lib.orc_set_threads.argtypes = [C.c_int]
+_lib.orc_set_threads.restype = None
 _lib.orc_get_lk_sum_mode.argtypes = []
 _lib.orc_get_lk_sum_mode.restype = C.c_int
 _lib.orc_p3p_set_polish.argtypes = [C.c_int]
@@ -191,6 +195,62 @@ def pyrlk(prev, nxt, pts, win=21, max_level=4, max_count=30, epsilon=0.01, min_e
     if rc != 0:
         raise RuntimeError("orc_pyrlk rc=%d" % rc)
     return out, status, err
+
+
+class Baseline:
+    """What the cpu_baseline leg of bench.py times: one cv::calcOpticalFlowPyrLK-equivalent per call (both pyramids,
+    the first image's Scharr planes, the LK loop) through raw ctypes calls on a library of its own.  That library is
+    this same source built for AVX2-class CPUs (libktlvo_oracle_v3.so) when the host has them, else the checker
+    build; -ffp-contract=off in both, so the results are the checker's."""
+
+    def __init__(self):
+        flags = ""
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("flags"):
+                    flags = line
+                    break
+        except OSError:
+            pass
+        v3 = os.path.join(_HERE, "libktlvo_oracle_v3.so")
+        ok = all((" " + f + " ") in (flags.replace("\n", " ") + " ") for f in ("avx2", "bmi2", "fma", "movbe", "f16c"))
+        self.build = "-O3 -march=x86-64-v3" if ok and os.path.exists(v3) else "-O3 -march=x86-64-v2"
+        self.lib = C.CDLL(v3) if ok and os.path.exists(v3) else _lib
+        L = self.lib
+        L.orc_pyramid_create.argtypes = _lib.orc_pyramid_create.argtypes
+        L.orc_pyramid_create.restype = C.c_void_p
+        L.orc_pyramid_destroy.argtypes = [C.c_void_p]
+        L.orc_pyramid_destroy.restype = None
+        L.orc_pyrlk.argtypes = _lib.orc_pyrlk.argtypes
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads.restype = None
+        L.orc_set_lk_sum_mode.argtypes = [C.c_int]
+        L.orc_set_lk_sum_mode.restype = None
+
+    def track_pair(self, a, b, pts, max_level=4, win=21, threads=1, sums=SUMS_SERIAL):
+        """Returns (next points, status, err) of one pair; every stage cut over `threads` threads."""
+        L = self.lib
+        a, b = _img(a), _img(b)
+        h, w = a.shape
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        n = pts.shape[0]
+        out, status, err = np.zeros((n, 2), np.float32), np.zeros(n, np.uint8), np.zeros(n, np.float32)
+        L.orc_set_threads(threads)
+        L.orc_set_lk_sum_mode(sums)
+        try:
+            pa = L.orc_pyramid_create(a, w, h, w, max_level, win, 1)
+            pb = L.orc_pyramid_create(b, w, h, w, max_level, win, 0)
+            try:
+                rc = L.orc_pyrlk(pa, pb, pts, n, out, status, err, win, max_level, 30, 0.01, 1e-4, threads)
+            finally:
+                L.orc_pyramid_destroy(pa)
+                L.orc_pyramid_destroy(pb)
+        finally:
+            L.orc_set_threads(1)
+            L.orc_set_lk_sum_mode(SUMS_SERIAL)
+        if rc != 0:
+            raise RuntimeError("orc_pyrlk rc=%d" % rc)
+        return out, status, err
 
 
 def lk_iterations(prev, nxt, pts, max_level=4, **kw):
@@ -301,13 +361,15 @@ def gao_quartic(a, b, p, q, r):
     return c
 
 
-SUMS_SERIAL, SUMS_FOUR_LANES, SUMS_PAIRWISE, SUMS_EXACT = 0, 1, 2, 3
-
-
 def set_lk_sum_mode(mode):
     """Rounding of the LK window sums: 0 serial float accumulator (OpenCV's scalar path; default), 1 four float
     accumulators, 2 pairwise float sum, 3 exact integer total rounded to float once (order-independent)."""
     _lib.orc_set_lk_sum_mode(int(mode))
+
+
+def set_threads(n):
+    """Threads the image-wide stages (pyramid levels, borders, Scharr) are cut over; results do not depend on it."""
+    _lib.orc_set_threads(int(n))
 
 
 def get_lk_sum_mode():

@@ -20,7 +20,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <limits>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -39,57 +43,161 @@ inline int reflect101(int p, int n) {
 inline int cv_round(double v) { return (int)lrint(v); }   /* round-half-even */
 inline int cv_floor(float v) { return (int)std::floor(v); }
 
+/* storage that is not cleared when it is made (every element is written by the code that fills it) */
+template <class T>
+struct Raw {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void alloc(size_t count) { p.reset(new T[count]); n = count; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+};
+
 struct Level {
     int w = 0, h = 0, pad = 0;
     int pitch = 0;                 /* padded row length in pixels */
-    std::vector<uint8_t> img;      /* (h+2pad) x pitch, reflect-101 border */
-    std::vector<int16_t> deriv;    /* (h+2pad) x pitch x 2, zero border */
+    Raw<uint8_t> img;              /* (h+2pad) x pitch, reflect-101 border */
+    Raw<int16_t> deriv;            /* (h+2pad) x pitch x 2, zero border */
     const uint8_t *ipx(int x, int y) const { return &img[(size_t)(y + pad) * pitch + (x + pad)]; }
     const int16_t *dpx(int x, int y) const { return &deriv[((size_t)(y + pad) * pitch + (x + pad)) * 2]; }
 };
 
-void pyr_down_impl(const uint8_t *src, int w, int h, int ss, uint8_t *dst, int ds) {
-    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
-    std::vector<int> rowbuf((size_t)5 * dw);
-    /* straightforward 2-D form; integer arithmetic, so any evaluation order is exact */
-    for (int y = 0; y < dh; y++) {
-        for (int j = 0; j < 5; j++) {
-            const uint8_t *s = src + (size_t)reflect101(2 * y + j - 2, h) * ss;
-            int *r = &rowbuf[(size_t)j * dw];
-            for (int x = 0; x < dw; x++) {
-                int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x;
-                int x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
-                r[x] = s[x0] + 4 * s[x1] + 6 * s[x2] + 4 * s[x3] + s[x4];
-            }
+/* A fixed set of worker threads that run ranges of a loop, the way cv::parallel_for_ hands stripes of a Range to
+ * its pool (featureTracking.cpp:205 reaches it through calcOpticalFlowPyrLK).  Workers are made once and kept:
+ * spawning threads per pyramid level costs more than a level's work at the upper levels. */
+class Pool {
+public:
+    static Pool &get() {
+        static Pool p;
+        return p;
+    }
+    /* fn(i0, i1) over [0, n) cut into `parts` ranges, taken one after the other by `threads` threads (the caller's
+     * among them) until none is left */
+    void run(int n, int parts, int threads, const std::function<void(int, int)> &fn) {
+        if (n <= 0) return;
+        parts = std::max(1, std::min(parts, n));
+        threads = std::max(1, std::min(threads, parts));
+        if (threads == 1) {
+            fn(0, n);
+            return;
         }
-        for (int x = 0; x < dw; x++) {
-            int v = rowbuf[x] + 4 * rowbuf[dw + x] + 6 * rowbuf[2 * dw + x] + 4 * rowbuf[3 * dw + x] +
-                    rowbuf[4 * dw + x];
-            dst[(size_t)y * ds + x] = (uint8_t)((v + 128) >> 8);
+        std::lock_guard<std::mutex> call(call_mutex_); /* one loop at a time */
+        while ((int)th_.size() < threads - 1) th_.emplace_back([this] { work(); });
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn; n_ = n; parts_ = parts; next_ = 0; finished_ = 0; helpers_ = 0; max_helpers_ = threads - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return finished_ == parts_; });
+        fn_ = nullptr;
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+
+private:
+    void drain() {
+        for (;;) {
+            int part, n, parts;
+            const std::function<void(int, int)> *fn;
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (next_ >= parts_) return;
+                part = next_++; n = n_; parts = parts_; fn = fn_;
+            }
+            (*fn)((int)((long long)n * part / parts), (int)((long long)n * (part + 1) / parts));
+            std::lock_guard<std::mutex> g(m_);
+            if (++finished_ == parts_) done_.notify_one();
         }
     }
+    void work() {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (helpers_ >= max_helpers_) continue; /* this loop asked for fewer threads than the pool holds */
+                helpers_++;
+            }
+            drain();
+        }
+    }
+    std::mutex call_mutex_, m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(int, int)> *fn_ = nullptr;
+    int n_ = 0, parts_ = 0, next_ = 0, finished_ = 0, helpers_ = 0, max_helpers_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
+int g_threads = 1; /* threads the image-wide stages (pyramid levels, borders, Scharr) are cut over; orc_pyrlk has its own argument */
+
+void pyr_down_impl(const uint8_t *src, int w, int h, int ss, uint8_t *dst, int ds) {
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    /* straightforward 2-D form; integer arithmetic, so any evaluation order is exact.  Output rows are independent:
+     * each thread takes a range of them with its own five row buffers. */
+    Pool::get().run(dh, g_threads, g_threads, [&](int y_from, int y_to) {
+        std::vector<int> rowbuf((size_t)5 * dw);
+        for (int y = y_from; y < y_to; y++) {
+            for (int j = 0; j < 5; j++) {
+                const uint8_t *s = src + (size_t)reflect101(2 * y + j - 2, h) * ss;
+                int *r = &rowbuf[(size_t)j * dw];
+                const int x_in0 = std::min(dw, 1), x_in1 = std::max(x_in0, (w - 3) / 2 + 1 > dw ? dw : (w - 3) / 2 + 1);
+                for (int x = 0; x < dw; x++) {
+                    if (x >= x_in0 && x < x_in1) { /* 2x - 2 >= 0 and 2x + 2 <= w - 1: no reflection */
+                        const uint8_t *c = s + 2 * x;
+                        r[x] = c[-2] + 4 * c[-1] + 6 * c[0] + 4 * c[1] + c[2];
+                        continue;
+                    }
+                    int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x;
+                    int x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
+                    r[x] = s[x0] + 4 * s[x1] + 6 * s[x2] + 4 * s[x3] + s[x4];
+                }
+            }
+            for (int x = 0; x < dw; x++) {
+                int v = rowbuf[x] + 4 * rowbuf[dw + x] + 6 * rowbuf[2 * dw + x] + 4 * rowbuf[3 * dw + x] +
+                        rowbuf[4 * dw + x];
+                dst[(size_t)y * ds + x] = (uint8_t)((v + 128) >> 8);
+            }
+        }
+    });
 }
 
 void scharr_impl(const uint8_t *src, int w, int h, int ss, int16_t *dst, int dpitch /* in pairs */) {
-    std::vector<int> t0(w + 2), t1(w + 2);
-    for (int y = 0; y < h; y++) {
-        const uint8_t *r0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * ss;
-        const uint8_t *r1 = src + (size_t)y * ss;
-        const uint8_t *r2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * ss;
-        int *a = &t0[1], *b = &t1[1];
-        for (int x = 0; x < w; x++) {
-            a[x] = (r0[x] + r2[x]) * 3 + r1[x] * 10;
-            b[x] = r2[x] - r0[x];
+    Pool::get().run(h, g_threads, g_threads, [&](int y_from, int y_to) {
+        std::vector<int> t0(w + 2), t1(w + 2);
+        for (int y = y_from; y < y_to; y++) {
+            const uint8_t *r0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * ss;
+            const uint8_t *r1 = src + (size_t)y * ss;
+            const uint8_t *r2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * ss;
+            int *a = &t0[1], *b = &t1[1];
+            for (int x = 0; x < w; x++) {
+                a[x] = (r0[x] + r2[x]) * 3 + r1[x] * 10;
+                b[x] = r2[x] - r0[x];
+            }
+            int x0 = w > 1 ? 1 : 0, x1 = w > 1 ? w - 2 : 0;
+            a[-1] = a[x0]; a[w] = a[x1];
+            b[-1] = b[x0]; b[w] = b[x1];
+            int16_t *d = dst + (size_t)y * dpitch * 2;
+            for (int x = 0; x < w; x++) {
+                d[2 * x] = (int16_t)(a[x + 1] - a[x - 1]);
+                d[2 * x + 1] = (int16_t)((b[x + 1] + b[x - 1]) * 3 + b[x] * 10);
+            }
         }
-        int x0 = w > 1 ? 1 : 0, x1 = w > 1 ? w - 2 : 0;
-        a[-1] = a[x0]; a[w] = a[x1];
-        b[-1] = b[x0]; b[w] = b[x1];
-        int16_t *d = dst + (size_t)y * dpitch * 2;
-        for (int x = 0; x < w; x++) {
-            d[2 * x] = (int16_t)(a[x + 1] - a[x - 1]);
-            d[2 * x + 1] = (int16_t)((b[x + 1] + b[x - 1]) * 3 + b[x] * 10);
-        }
-    }
+    });
 }
 
 }  // namespace
@@ -99,6 +207,8 @@ struct orc_pyramid {
     int win = 21;
     bool with_deriv = false;
 };
+
+extern "C" void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n > 256 ? 256 : n; }
 
 extern "C" void orc_pyr_down(const uint8_t *src, int w, int h, int ss, uint8_t *dst, int ds) {
     pyr_down_impl(src, w, h, ss, dst, ds);
@@ -115,30 +225,38 @@ extern "C" orc_pyramid *orc_pyramid_create(const uint8_t *img, int w, int h, int
     p->win = win;
     p->with_deriv = with_deriv != 0;
     int lw = w, lh = h;
-    std::vector<uint8_t> cur((size_t)w * h), nxt;
+    Raw<uint8_t> cur, nxt;
+    cur.alloc((size_t)w * h);
     for (int y = 0; y < h; y++) memcpy(&cur[(size_t)y * w], img + (size_t)y * stride, w);
     for (int level = 0; level <= max_level; level++) {
         Level L;
         L.w = lw; L.h = lh; L.pad = win; L.pitch = lw + 2 * win;
-        L.img.resize((size_t)(lh + 2 * win) * L.pitch);
+        L.img.alloc((size_t)(lh + 2 * win) * L.pitch);
         /* copyMakeBorder(..., BORDER_REFLECT_101 | BORDER_ISOLATED) */
-        for (int y = -win; y < lh + win; y++) {
-            const uint8_t *s = &cur[(size_t)reflect101(y, lh) * lw];
-            uint8_t *d = &L.img[(size_t)(y + win) * L.pitch];
-            for (int x = -win; x < lw + win; x++) d[x + win] = s[reflect101(x, lw)];
-        }
+        Pool::get().run(lh + 2 * win, g_threads, g_threads, [&](int r_from, int r_to) {
+            for (int y = r_from - win; y < r_to - win; y++) {
+                const uint8_t *s = &cur[(size_t)reflect101(y, lh) * lw];
+                uint8_t *d = &L.img[(size_t)(y + win) * L.pitch];
+                for (int x = -win; x < 0; x++) d[x + win] = s[reflect101(x, lw)];
+                memcpy(d + win, s, lw);
+                for (int x = lw; x < lw + win; x++) d[x + win] = s[reflect101(x, lw)];
+            }
+        });
         if (with_deriv) {
             /* calcSharrDeriv into the interior, copyMakeBorder(BORDER_CONSTANT) -> zero frame */
-            L.deriv.assign((size_t)(lh + 2 * win) * L.pitch * 2, 0);
+            L.deriv.alloc((size_t)(lh + 2 * win) * L.pitch * 2);
+            Pool::get().run(lh + 2 * win, g_threads, g_threads, [&](int r_from, int r_to) {
+                memset(&L.deriv[(size_t)r_from * L.pitch * 2], 0, (size_t)(r_to - r_from) * L.pitch * 2 * sizeof(int16_t));
+            });
             scharr_impl(cur.data(), lw, lh, lw, &L.deriv[((size_t)win * L.pitch + win) * 2], L.pitch);
         }
         p->levels.push_back(std::move(L));
         if (level == max_level) break;
         int nw = (lw + 1) / 2, nh = (lh + 1) / 2;
         if (nw <= win || nh <= win) break; /* buildOpticalFlowPyramid stops here */
-        nxt.assign((size_t)nw * nh, 0);
+        nxt.alloc((size_t)nw * nh);
         pyr_down_impl(cur.data(), lw, lh, lw, nxt.data(), nw);
-        cur.swap(nxt);
+        std::swap(cur, nxt);
         lw = nw; lh = nh;
     }
     return p;
@@ -366,19 +484,11 @@ extern "C" int orc_pyrlk(const orc_pyramid *prev, const orc_pyramid *next, const
         const Level &I = prev->levels[level];
         const Level &J = next->levels[level];
         if (I.w != J.w || I.h != J.h) return -3;
-        if (nthreads == 1) {
-            range_fn(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count, epsSq, min_eig_thr, 0, n);
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nthreads; t++) {
-                int i0 = (int)((long long)n * t / nthreads), i1 = (int)((long long)n * (t + 1) / nthreads);
-                th.emplace_back([&, i0, i1]() {
-                    range_fn(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count, epsSq, min_eig_thr,
-                             i0, i1);
-                });
-            }
-            for (auto &t : th) t.join();
-        }
+        /* stripes of the point range per level, as LKTrackerInvoker's parallel_for_ has them; more stripes than
+         * threads, because iteration counts differ widely between points */
+        Pool::get().run(n, nthreads * 4, nthreads, [&](int i0, int i1) {
+            range_fn(I, J, prev_xy, next_xy, status, err, level, maxLevel, win, max_count, epsSq, min_eig_thr, i0, i1);
+        });
     }
     return 0;
 }

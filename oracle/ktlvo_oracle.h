@@ -45,6 +45,9 @@ int orc_pyramid_deriv_copy(const orc_pyramid *p, int level, int16_t *dst /* 2*w*
 /* Order of the float additions inside orc_pyrlk's window sums (process-wide): 0 = one accumulator in
  * raster order (default; LKTrackerInvoker's scalar path), 1 = four accumulators in turn along a row (a
  * 4-lane SIMD build), 2 = pairwise.  For measuring the sensitivity of LK results to rounding order. */
+/* Threads the image-wide stages (pyrDown, border copies, calcSharrDeriv) of the calls below are cut over
+ * (process-wide, default 1).  Results do not depend on it: the work is integer and rows are independent. */
+void orc_set_threads(int n);
 void orc_set_lk_sum_mode(int mode);
 int orc_get_lk_sum_mode(void);
 

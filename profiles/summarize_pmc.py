@@ -16,6 +16,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLOCK_MIN_US = 100.0   # shortest launch whose GRBM_GUI_ACTIVE / 8 / duration is taken for the shader clock
 
 
 def main():
@@ -30,12 +31,18 @@ def main():
                 ns = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                 if ns > 0:   # the counter is summed over the 8 XCDs: shader clock = cycles / 8 / duration
                     agg[k]["clock_ghz"].append(float(r["Counter_Value"]) / 8.0 / ns)
+                    agg[k]["duration_us_under_counters"].append(ns / 1e3)
     res = {}
     for k, d in agg.items():
         if k.startswith(("at::", "void at::", "__amd")):
             continue
         e = {c: sum(v) / len(v) for c, v in d.items()}
         e["launches_sampled"] = max(len(v) for v in d.values())
+        # GRBM_GUI_ACTIVE also counts the cycles around a launch in which the front end is busy with it; over a launch of
+        # a millisecond that is nothing, over a launch of some ten microseconds it is most of the count, and the
+        # quotient is no clock.  Short launches get none.
+        if "clock_ghz" in e and e.get("duration_us_under_counters", 0.0) < CLOCK_MIN_US:
+            e["clock_ghz"] = None
         if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
             e["hbm_read_bytes_per_launch"] = 2.0 * e.get("FETCH_SIZE", 0.0) * 1024.0
             e["hbm_write_bytes_per_launch"] = e.get("WRITE_SIZE", 0.0) * 1024.0

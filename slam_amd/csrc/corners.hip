@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256) void corner_select(SelArgs a) {
         const int cnt = vcnt[ci];
         if (cnt >= 4) { // cannot happen for cell = round(min_dist); reported instead of dropped
             if (tid == 0) *a.overflow = 2;
+            ncorners = -1;
             break;
         }
         if (tid == 0) {

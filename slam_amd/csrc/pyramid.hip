@@ -415,7 +415,7 @@ extern "C" int ktlvo_upload_image(ktlvo_ctx *ctx, int slot, const uint8_t *img, 
 
 namespace ktlvo {
 // Staging buffer k of the batch uploads, at least `bytes` large and no longer read by an earlier ingest launch.
-static int stage_take(ktlvo_ctx *ctx, size_t bytes, int k, bool want_pinned) {
+static int stage_take(ktlvo_ctx *ctx, size_t bytes, int k, bool want_pinned, bool want_device = true) {
     StageRing &r = ctx->stage;
     if (bytes > r.batch_bytes) { // grow: every buffer goes, and each comes back on its next use
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -429,7 +429,7 @@ static int stage_take(ktlvo_ctx *ctx, size_t bytes, int k, bool want_pinned) {
         }
         r.batch_bytes = bytes;
     }
-    if (!r.d_batch[k]) KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch[k], r.batch_bytes));
+    if (want_device && !r.d_batch[k]) KTLVO_HIP(ctx, hipMalloc((void **)&r.d_batch[k], r.batch_bytes));
     if (want_pinned && !r.h_batch[k]) KTLVO_HIP(ctx, hipHostMalloc((void **)&r.h_batch[k], r.batch_bytes, hipHostMallocDefault));
     if (!r.batch_done[k]) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.batch_done[k], hipEventDisableTiming));
     if (!r.copy_done[k]) KTLVO_HIP(ctx, hipEventCreateWithFlags(&r.copy_done[k], hipEventDisableTiming));
@@ -501,7 +501,7 @@ int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const 
     const size_t bytes = (size_t)w * h, img_stride = (bytes + 255) & ~(size_t)255;
     StageRing &r = ctx->stage;
     const bool pinned = is_pinned(a) && is_pinned(b);
-    int rc = stage_take(ctx, 2 * img_stride, 0, !pinned);
+    int rc = stage_take(ctx, 2 * img_stride, 0, !pinned, false); // (a device staging buffer only if the DMA route is taken)
     if (rc != KTLVO_OK) return rc;
     const uint8_t *ha = a, *hb = b;
     if (!pinned) {
@@ -516,6 +516,8 @@ int upload_pair(ktlvo_ctx *ctx, int slot_a, int slot_b, const uint8_t *a, const 
                            (const uint8_t *)db, w);
     } else {
         (void)hipGetLastError();
+        rc = stage_take(ctx, 2 * img_stride, 0, !pinned, true);
+        if (rc != KTLVO_OK) return rc;
         uint8_t *d = r.d_batch[0];
         KTLVO_HIP(ctx, hipMemcpyAsync(d, ha, bytes, hipMemcpyHostToDevice, ctx->stream));
         KTLVO_HIP(ctx, hipMemcpyAsync(d + img_stride, hb, bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -74,10 +74,17 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     const ktlvo_config &c = ctx->cfg;
     const int W = c.width, H = c.height;
 
+    // Once upload_pair has queued the ingest launch, the device may be reading the caller's (pinned) frames, and the
+    // pinned block h_io may be in flight: every return after that point comes after the stream has been waited for, the
+    // failing ones too, so that the buffers are the caller's again whatever the call returns.
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return code;
+    };
     if (!t->inited) { // :349-356
-        if ((rc = upload_pair(ctx, t->sCurL, t->sCurR, left, right, W, H)) != KTLVO_OK) return rc;
+        if ((rc = upload_pair(ctx, t->sCurL, t->sCurR, left, right, W, H)) != KTLVO_OK) return fail(rc);
         const int s[2] = {t->sCurL, t->sCurR};
-        if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
+        if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return fail(rc);
         // the caller may reuse (pinned) frame buffers as soon as this call returns
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         t->inited = true;
@@ -94,10 +101,10 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         t->sLastL = sLL; t->sLastR = sLR; t->sCurL = sCL; t->sCurR = sCR;
         t->imagePointsCur.swap(newPointsCur);
     };
-    if ((rc = upload_pair(ctx, sCL, sCR, left, right, W, H)) != KTLVO_OK) return rc;
+    if ((rc = upload_pair(ctx, sCL, sCR, left, right, W, H)) != KTLVO_OK) return fail(rc);
     {
         const int s[2] = {sCL, sCR};
-        if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return rc;
+        if ((rc = ktlvo_build_pyramids(ctx, s, 2, c.max_level, c.win)) != KTLVO_OK) return fail(rc);
     }
 
     std::vector<float> featuresLastLeft; // :385-389
@@ -124,7 +131,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
         std::vector<int> counts(n_roi);
         const ktlvo_gftt_params gp = {capr, 0.01, 10, 3, 1, 0.0}; // GFTTDetector::create(100,0.01,10,3,true,0.0), :103
         rc = ktlvo_detect_gftt(ctx, sLL, rois.data(), n_roi, &gp, xy.data(), resp.data(), counts.data(), capr);
-        if (rc != KTLVO_OK) return rc;
+        if (rc != KTLVO_OK) return fail(rc);
         std::vector<float> kxy, kresp;
         for (int r = 0; r < n_roi; r++)
             for (int k = 0; k < counts[r]; k++) { // :423-428
@@ -133,16 +140,16 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
                 kresp.push_back(0.f); // OpenCV 3 GFTTDetector: KeyPoint(pt, blockSize), response stays 0
             }
         int nk = (int)kresp.size();
-        if (nk > c.max_points) return KTLVO_ERR_CAPACITY;
+        if (nk > c.max_points) return fail(KTLVO_ERR_CAPACITY);
         rc = ktlvo_anms(ctx, kxy.data(), kresp.data(), &nk, c.anms_keep); // :433
-        if (rc != KTLVO_OK) return rc;
+        if (rc != KTLVO_OK) return fail(rc);
         featuresLastLeft.assign(kxy.begin(), kxy.begin() + 2 * (size_t)nk); // :434
         newKeyFrame = true;
     }
     if (new_key_frame) *new_key_frame = newKeyFrame ? 1 : 0;
 
     const int N = (int)(featuresLastLeft.size() / 2);
-    if (N > c.max_points) return KTLVO_ERR_CAPACITY;
+    if (N > c.max_points) return fail(KTLVO_ERR_CAPACITY);
     if (N == 0) { // nothing to track: the uploads still have to finish before the caller's buffers are free again
         KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
         commit();
@@ -166,7 +173,10 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
     // on a GPU that a frame's few thousand points leave mostly idle, and the chain of dependent launches
     // that sets the frame's latency is two tracks long instead of three.
     memcpy(t->h_io, featuresLastLeft.data(), (size_t)N * 8); // the previous frame's read of h_io ended with its sync
-    KTLVO_HIP(ctx, hipMemcpyAsync(dA, t->h_io, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+        const hipError_t e = hipMemcpyAsync(dA, t->h_io, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(set_hip_error(ctx, e, "hipMemcpyAsync(points)", __FILE__, __LINE__));
+    }
     // With the reference's five pyramid levels all six tracks come from one launch (pyrlk_frame_chain: a wave per
     // chain of two tracks, so the frame waits for its slowest chain rather than for the slowest track of each stage
     // in turn); otherwise from a launch per stage.
@@ -179,7 +189,7 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
             pl.prev[1] = (uint16_t)sLL; pl.next[1] = (uint16_t)sCL;
             const int po[2] = {0, 0}, no[2] = {0, N};
             rc = launch_pyrlk_ex(ctx, pl, 2, dA, po, dBC, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
-            if (rc != KTLVO_OK) return rc;
+            if (rc != KTLVO_OK) return fail(rc);
         }
         { // LR->CR from featuresPrevRight, CL->CR from featuresCurLeft (:462-467); and the backward tracks of both
           // getOpticalFlow stages (:214 as reached from :509 and :513): LR->LL and CL->LL from the same two lists
@@ -192,14 +202,17 @@ extern "C" int ktlvo_track_stereo_frame(ktlvo_ctx *ctx, const uint8_t *left, con
             rc = launch_pyrlk_ex(ctx, pl, 4, dBC, po, dDE, no, ctx->d_status, ctx->d_err, N, nullptr, &lk);
         }
     }
-    if (rc != KTLVO_OK) return rc;
+    if (rc != KTLVO_OK) return fail(rc);
     // :486-501 circular check, :509 getOpticalFlow(LastLeft, LastRight, y threshold 1), :513 getOpticalFlow(LastLeft,
     // CurLeft, y threshold 5): kept-index lists of the three and the survivors' featuresLastLeftSelect,
     // featuresCurLeftSelect, featuresLastRightSelect
     rc = launch_frame_gates(ctx, dA, dB, dC, dD, dE, dCHK, dCHKB, N, dK1, dK2, dK3, dCnt, dU1, dU2, dU3);
-    if (rc != KTLVO_OK) return rc;
+    if (rc != KTLVO_OK) return fail(rc);
     // One copy and one synchronisation for the whole frame (36 N + 32 bytes into pinned memory).
-    KTLVO_HIP(ctx, hipMemcpyAsync(t->h_io, t->d_out, TS::out_ints(N) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    {
+        const hipError_t e = hipMemcpyAsync(t->h_io, t->d_out, TS::out_ints(N) * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) return fail(set_hip_error(ctx, e, "hipMemcpyAsync(results)", __FILE__, __LINE__));
+    }
     KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int *cnt = t->h_io, *K1 = cnt + 8, *K2 = K1 + N, *K3 = K2 + N;
     const float *U1 = (const float *)(K3 + N), *U2 = U1 + 2 * (size_t)N, *U3 = U2 + 2 * (size_t)N;

@@ -54,3 +54,26 @@ def test_round_robin_batch_equals_single_rank_run(tmp_path):
     assert a.shape == (6, 5) and a.tobytes() == b.tobytes()
     assert o1["pair_table_crc32"] == o2["pair_table_crc32"]
     assert (a[:, 2] > 200).all() and len(set(a[:, 4].tolist())) == 6     # every pair tracked, every pair different
+
+
+def test_batch_smaller_than_the_rank_count(tmp_path):
+    """Two frame pairs dealt to three ranks: the third owns nothing, builds nothing, launches nothing, and still takes
+    part in the barrier, the all_gather and the all_reduce; the table is the single-rank table."""
+    common = ["bench.py", "--workload", "batch", "--batch-pairs", "2", "--width", "640", "--height", "360", "--features",
+              "400", "--steps", "2", "--warmup", "1"]
+    three, one = tmp_path / "three.npy", tmp_path / "one.npy"
+    o3 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr",
+               "127.0.0.1", "--master-port", "29645"] + common + ["--gpus", "3", "--dump-pairs", str(three)],
+              {"KTLVO_BENCH_REHEARSAL": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    o1 = _run([sys.executable] + common + ["--dump-pairs", str(one)])
+    assert o3["n_gpus"] == 3 and o3["config"]["pairs_per_rank"] == [1, 1, 0]
+    assert o3["per_rank"][2]["features_in"] == 0 and o3["per_rank"][2]["tracked"] == 0
+    assert np.load(three).tobytes() == np.load(one).tobytes() and o3["pair_table_crc32"] == o1["pair_table_crc32"]
+    assert o3["value"] > 0
+
+
+def test_sequence_workload_at_the_benchmark_frame_size(tmp_path):
+    """BASELINE configs[0]/[3] name 1241x376 frames: the sequence workload takes the size from the command line."""
+    o = _run([sys.executable, "bench.py", "--workload", "sequence", "--frames", "6", "--width", "1241", "--height", "376"])
+    assert "1241x376" in o["metric"] and o["per_rank"][0]["tracked_points"] > 500
+    assert o["per_rank"][0]["ate_rmse_m"] < 0.1

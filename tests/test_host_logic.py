@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -125,6 +126,68 @@ def test_gather_world_size_2_gloo():
     assert np.array_equal(np.stack(single), recs)
 
 
+def _pair_worker_n(rank, world, port, q, n_items):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_round_robin(n_items, rank, world)
+    rows = torch.tensor([[p, 100, 90 + p, 1000 + p, 2000 + p] for p in mine], dtype=torch.int64).reshape(-1, 5)
+    table = shard.gather_pair_records(rows, n_items, world)
+    # a rank without pairs still reports: zero features, zero tracked, its own elapsed time
+    rec = torch.tensor([100.0 * len(mine), 90.0 * len(mine), float(len(mine)), 0.5 * len(mine), float(len(mine) > 0), 0.0, 0.0,
+                        0.01 * (rank + 1)], dtype=torch.float64)
+    recs = shard.gather_records(rec, world)
+    t_max = shard.max_over_ranks(0.01 * (rank + 1), torch.device("cpu"), world)
+    traj = shard.gather_trajectories(torch.full((3, 16), float(rank), dtype=torch.float32), world)
+    dist.barrier()
+    if rank == 0:
+        q.put((table, recs, t_max, traj))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [6, 8, 19])
+def test_gathers_world_size_8_gloo(n_items):
+    """Eight ranks, as the 8-GPU node runs them: a batch smaller than the rank count (6 pairs: two ranks own nothing
+    and contribute an all-padding block and a zero record), one pair each, and an uneven deal.  The pair table equals
+    the single-rank table, the per-rank records and trajectories arrive in rank order, the time is the slowest rank's."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker_n, args=(r, world, port, q, n_items)) for r in range(world)]
+    for p in procs:
+        p.start()
+    table, recs, t_max, traj = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    rows = torch.tensor([[p, 100, 90 + p, 1000 + p, 2000 + p] for p in range(n_items)], dtype=torch.int64)
+    assert np.array_equal(table, shard.gather_pair_records(rows, n_items, 1))
+    owned = [len(shard.shard_round_robin(n_items, r, world)) for r in range(world)]
+    assert sum(owned) == n_items and (min(owned) == 0) == (n_items < world)
+    assert recs.shape == (world, 8) and list(recs[:, 2]) == [float(k) for k in owned]
+    assert abs(t_max - 0.08) < 1e-12
+    agg = shard.aggregate(recs, 10, t_max)
+    assert agg["tracked_per_step"] == 90.0 * n_items and abs(agg["value"] - 90.0 * n_items * 10 / 0.08) < 1e-6
+    assert traj.shape == (world, 3, 16) and all((traj[r] == r).all() for r in range(world))
+
+
+def test_avx2_build_of_the_oracle_equals_the_checker_build():
+    """bench.py times a build of the oracle made for AVX2-class CPUs; with -ffp-contract=off in both builds its
+    results must be the checker's bit for bit, in every reading of the window sums, on any number of threads."""
+    import oracle as O
+    from slam_amd import synth
+    a, b = synth.texture_pair(320, 240, 5, 1.5, -0.5, noise=True)
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(-10, 330, 300), rng.uniform(-10, 250, 300)], 1).astype(np.float32)
+    base = O.Baseline()
+    for sums in (O.SUMS_SERIAL, O.SUMS_FOUR_LANES, O.SUMS_EXACT):
+        ref = O.pyrlk(a, b, pts, sums=sums)
+        for threads in (1, 3):
+            got = base.track_pair(a, b, pts, threads=threads, sums=sums)
+            assert all(np.array_equal(x, y) for x, y in zip(got, ref)), (sums, threads)
+
+
 def test_parallel_frame_renderer_matches_serial():
     """bench.py renders its input frames in helper processes; they must be the serial renderer's."""
     from slam_amd import synth
@@ -154,3 +217,4 @@ def test_bench_cpu_baseline_leg_runs_on_the_host():
     out = bench.cpu_baseline([a, b], pts, 4, 0.2)
     assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
     assert len(out["lk_iterations_per_level_mean"]) >= 3 and out["single_thread"]["value"] > 0
+    assert out["four_accumulators"]["value"] > 0 and out["all_cores_over_one_thread"] > 0 and "-O3" in out["build"]

@@ -61,3 +61,60 @@ def test_noalloc_detect_matches_detect(make_ctx, klib):
     rc = ctx.detect_gftt_noalloc(0, [(30, 30, 100, 100)], p1, dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), 100)
     assert b"capacity" in klib.lib.ktlvo_strerror(rc)
     assert ctx.detect_gftt_noalloc(0, [], p1, None, None, None, 100) == 0
+
+
+def test_noalloc_on_a_fresh_context_allocates_nothing_and_captures_into_a_graph(make_ctx, klib):
+    """The entry point's contract, on a context that has made no other detection call (so nothing it needs was
+    allocated or warmed by one): free device memory is the same before and after the call, and the call can be
+    recorded into a HIP graph -- stream capture refuses allocation, synchronisation and copies from pageable memory --
+    whose replays give ktlvo_detect_gftt's corners."""
+    import torch
+    W, H = 640, 360
+    img = synth.texture_image(W, H, seed=21, noise=True)
+    img2 = synth.texture_image(W, H, seed=22, noise=True)
+    ctx = make_ctx(width=W, height=H)
+    ctx.upload_image(0, img)
+    ctx.sync()
+    rois = [(30 + 58 * j, 30 + 40 * i, 58, 40) for i in range(7) for j in range(10)]
+    p = klib.gftt_params(60, 0.01, 8.0, 3, 1, 0.0)
+    n, cap = len(rois), 60
+    d_xy = torch.zeros((n, cap, 2), dtype=torch.float32, device="cuda")
+    d_resp = torch.zeros((n, cap), dtype=torch.float32, device="cuda")
+    d_cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    rc = ctx.detect_gftt_noalloc(0, rois, p, d_xy.data_ptr(), d_resp.data_ptr(), d_cnt.data_ptr(), cap)   # the context's first detection
+    assert rc == 0, klib.strerror(rc)
+    ctx.sync()
+    assert torch.cuda.mem_get_info()[0] == free_before
+
+    def result():
+        cnt, xy, resp = d_cnt.cpu().numpy(), d_xy.cpu().numpy(), d_resp.cpu().numpy()
+        return [(xy[i, :cnt[i]].copy(), resp[i, :cnt[i]].copy()) for i in range(n)]
+    first = result()
+    # under stream capture
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        rc = ctx.detect_gftt_noalloc(0, rois, p, d_xy.data_ptr(), d_resp.data_ptr(), d_cnt.data_ptr(), cap)
+    assert rc == 0, klib.strerror(rc)
+    d_cnt.fill_(-3)
+    graph.replay()
+    torch.cuda.synchronize()
+    _same(result(), first)
+    ctx.upload_image(0, img2)          # another frame in the slot: the replayed kernels read it
+    ctx.sync()
+    graph.replay()
+    torch.cuda.synchronize()
+    second = result()
+    ctx.set_stream(None)
+    _same(first, make_other(make_ctx, W, H, img).detect_gftt(0, rois, p))
+    _same(second, ctx.detect_gftt(0, rois, p))
+    assert sum(len(x) for x, _ in first) > 300 and not all(np.array_equal(a[0], b[0]) for a, b in zip(first, second))
+
+
+def make_other(make_ctx, W, H, img):
+    c = make_ctx(width=W, height=H)
+    c.upload_image(0, img)
+    return c
