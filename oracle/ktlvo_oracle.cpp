@@ -43,16 +43,74 @@ inline int reflect101(int p, int n) {
 inline int cv_round(double v) { return (int)lrint(v); }   /* round-half-even */
 inline int cv_floor(float v) { return (int)std::floor(v); }
 
+/* Blocks of a few sizes come and go with every pyramid (a frame stream builds two per call, always of the same
+ * sizes); fresh blocks of that size come from the kernel page by page, which costs a single thread more than filling
+ * them costs sixteen.  Freed blocks are kept by size and handed out again, as an image library's buffer pool does. */
+class BlockCache {
+public:
+    static BlockCache &get() {
+        static BlockCache c;
+        return c;
+    }
+    void *take(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].second == bytes) {
+                    void *p = free_[i].first;
+                    free_[i] = free_.back();
+                    free_.pop_back();
+                    return p;
+                }
+        }
+        return ::operator new(bytes);
+    }
+    void give(void *p, size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            if (free_.size() < 64 && bytes >= 4096) {
+                free_.emplace_back(p, bytes);
+                return;
+            }
+        }
+        ::operator delete(p);
+    }
+    ~BlockCache() {
+        for (auto &f : free_) ::operator delete(f.first);
+    }
+
+private:
+    std::mutex m_;
+    std::vector<std::pair<void *, size_t>> free_;
+};
+
 /* storage that is not cleared when it is made (every element is written by the code that fills it) */
 template <class T>
 struct Raw {
-    std::unique_ptr<T[]> p;
+    T *p = nullptr;
     size_t n = 0;
-    void alloc(size_t count) { p.reset(new T[count]); n = count; }
+    Raw() = default;
+    Raw(const Raw &) = delete;
+    Raw &operator=(const Raw &) = delete;
+    Raw(Raw &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Raw &operator=(Raw &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~Raw() { release(); }
+    void release() {
+        if (p) BlockCache::get().give(p, n * sizeof(T));
+        p = nullptr; n = 0;
+    }
+    void alloc(size_t count) {
+        release();
+        p = (T *)BlockCache::get().take(count * sizeof(T));
+        n = count;
+    }
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
-    T *data() { return p.get(); }
-    const T *data() const { return p.get(); }
+    T *data() { return p; }
+    const T *data() const { return p; }
 };
 
 struct Level {
