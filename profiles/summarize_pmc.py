@@ -53,7 +53,8 @@ def main():
         res[k] = e
     # the counters describe these versions of the kernel sources (bench.py ignores a summary whose hashes are stale)
     res["_source_sha1"] = {}
-    for rel in ("slam_amd/csrc/pyrlk.hip", "slam_amd/csrc/pyramid.hip", "slam_amd/csrc/corners.hip"):
+    for rel in ("slam_amd/csrc/pyrlk.hip", "slam_amd/csrc/pyramid.hip", "slam_amd/csrc/corners.hip",
+                "slam_amd/csrc/corners_candidates.hip", "slam_amd/csrc/corners_sort.hip", "slam_amd/csrc/corners_select.hip"):
         try:
             res["_source_sha1"][rel] = hashlib.sha1(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
         except OSError:

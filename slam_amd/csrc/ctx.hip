@@ -176,8 +176,6 @@ extern "C" ktlvo_ctx *ktlvo_create(const ktlvo_config *cfg, int device_id) {
         ctx->frame_chain = !(e && e[0] == '1');
         e = getenv("KTLVO_CANDIDATES_TILES");
         ctx->candidates_wave = !(e && e[0] == '1');
-        e = getenv("KTLVO_CANDIDATES_BANDS48");
-        ctx->candidates_low_bands = !(e && e[0] == '1');
         e = getenv("KTLVO_RELAX_TRIES");
         if (e && e[0] >= '0' && e[0] <= '9') ctx->relax_tries = std::min(atoi(e), 1024);
         e = getenv("KTLVO_GREEDY_SEQUENTIAL");

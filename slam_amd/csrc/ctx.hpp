@@ -107,7 +107,6 @@ struct ktlvo_ctx {
     bool pyr_per_level = false; // one pyrDown launch per level instead of the fused small-level kernel (A/B, tests)
     bool big_lds_select = false, big_lds_sort = false, big_lds_sort_buckets = false; // corner kernels that use more than 64 KiB of LDS have been enabled
     bool candidates_wave = true; // large ROIs take corner_candidates_wave (KTLVO_CANDIDATES_TILES=1 at creation: the LDS-tile kernel; A/B, tests)
-    bool candidates_low_bands = true; // small launches of the whole-frame candidates kernel take bands of fewer rows (KTLVO_CANDIDATES_BANDS48=1 at creation: always about 48; A/B)
     int relax_tries = 64; // times a candidate of the relaxation looks at its undecided predecessors again within a launch before it leaves the rest to the next one (KTLVO_RELAX_TRIES at creation: tests set 0 to see launches that do not settle)
     bool greedy_rounds = true;   // frames whose cell grid does not fit LDS take the greedy pass in rounds (KTLVO_GREEDY_SEQUENTIAL=1 at creation: a workgroup per frame walks the candidates; A/B, tests)
     bool frames_lds_sort = true; // whole frames are sorted in LDS, one workgroup per frame or per response range of a frame (KTLVO_FRAMES_GLOBAL_SORT=1 at creation: the bitonic network in global memory; A/B, tests)
