@@ -665,6 +665,10 @@ def main():
         o_next, o_status, o_err = outs[0]
 
         def full_step(side_by_side):
+            if side_by_side == "one_call":
+                ctx.detect_build_track_dev(prev_slots, next_slots, gp, d_cxy.data_ptr(), d_cr.data_ptr(), d_cc.data_ptr(), NF, slots,
+                                           o_next.data_ptr(), o_status.data_ptr(), o_err.data_ptr(), lk)
+                return
             if side_by_side:
                 ctx.detect_build_frames_dev(prev_slots, gp, d_cxy.data_ptr(), d_cr.data_ptr(), d_cc.data_ptr(), NF, slots)
             else:
@@ -694,19 +698,21 @@ def main():
         ref_bits = (o_next.clone(), o_status.clone())
         t_side = timed_full(True)
         assert torch.equal(o_next, ref_bits[0]) and torch.equal(o_status, ref_bits[1]), "side-by-side step differs"
+        t_one = timed_full("one_call")
+        assert torch.equal(o_next, ref_bits[0]) and torch.equal(o_status, ref_bits[1]), "one-call step differs"
         # ... and fed from the host: the step's frames uploaded from pinned memory every step (one DMA on the copy
         # stream under the previous step's kernels, one ingest launch), then detected, built and tracked: the whole
         # configs[1] stream as one number
         stream_full = None
         if not a.skip_stream:
             host_f = torch.from_numpy(np.stack(frames)).pin_memory()
-            t_sf = timed_full(True, host_f.numpy())
+            t_sf = timed_full("one_call", host_f.numpy())
             assert torch.equal(o_next, ref_bits[0]) and torch.equal(o_status, ref_bits[1]), "host-fed step differs"
             stream_full = {"ms_per_step": t_sf * 1e3, "value": tracked_full / t_sf, "unit": "tracked features/s",
                            "tracked_per_step": tracked_full,
                            "note": "per step: ktlvo_upload_images (all %d frames, %.1f MB, one DMA from pinned memory on the copy "
-                                   "stream + one ingest launch), ktlvo_detect_build_frames_dev (corners of the %d first frames and "
-                                   "all pyramids, side by side), ktlvo_pyrlk_batch_dev on the detected corners; one context "
+                                   "stream + one ingest launch), ktlvo_detect_build_track_dev (corners of the %d first frames and "
+                                   "all pyramids side by side, the LK launch on the detected corners behind them); one context "
                                    "running ahead of the device, every step's results identical to the resident step's"
                                    % (NI, NI * W * H / 1e6, NP)}
             del host_f
@@ -723,6 +729,11 @@ def main():
                                                       "value": tracked_full / t_side, "unit": "tracked features/s",
                                                       "arrangement": "ktlvo_detect_build_frames_dev (pyramid build on a side stream "
                                                                      "beside the detection), ktlvo_pyrlk_batch_dev"},
+                  "detect_build_track_one_call": {"ms_per_step": t_one * 1e3, "tracked_per_step": tracked_full,
+                                                  "value": tracked_full / t_one, "unit": "tracked features/s",
+                                                  "arrangement": "ktlvo_detect_build_track_dev: the side-by-side step with the LK "
+                                                                 "launch queued behind the detection before the host waits for "
+                                                                 "the detection's flags"},
                   "stream_full": stream_full,
                   "note": "ktlvo_detect_gftt_frames_dev: Shi-Tomasi corners (quality 0.01, minDistance %g, at most %d) of the "
                           "step's %d first frames in one call, output on the device; algorithmic bytes = W H per frame read + "

@@ -196,6 +196,16 @@ int ktlvo_detect_gftt_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames,
 int ktlvo_detect_build_frames_dev(ktlvo_ctx *ctx, const int *detect_slots, int n_frames, const ktlvo_roi *roi,
                                   const ktlvo_gftt_params *params, float *d_xy, float *d_response, int *d_counts,
                                   int cap, const int *build_slots, int n_build, int max_level, int win);
+/* The frame-pair stream's whole step in one call (featureTracking.cpp:408-430 detect, :457-479 track):
+ * ktlvo_detect_build_frames_dev(prev_slots, ..., build_slots) followed by ktlvo_pyrlk_batch_dev(prev_slots, next_slots,
+ * d_xy, cap, ...), with the same results.  The LK launch is queued behind the detection before the host waits for the
+ * detection's flags, so the device does not idle for that round trip; the call returns once the corners are final, the
+ * tracking results are complete in the order of the context's stream.  cap is the corner capacity per frame and the
+ * point count per pair (a frame with fewer corners tracks its list's unused tail too; d_counts says how many are real). */
+int ktlvo_detect_build_track_dev(ktlvo_ctx *ctx, const int *prev_slots, const int *next_slots, int n_pairs,
+                                 const ktlvo_roi *roi, const ktlvo_gftt_params *params, float *d_xy, float *d_response,
+                                 int *d_counts, int cap, const int *build_slots, int n_build, float *d_next_xy,
+                                 uint8_t *d_status, float *d_err, const ktlvo_lk_params *lk);
 /* The same detection for callers that must not allocate (code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  It calls no hipMalloc,
  * hipFree or other allocating routine, copies nothing and does not synchronise: the ROI list travels as

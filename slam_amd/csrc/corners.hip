@@ -273,8 +273,13 @@ static int select_large_lds(ktlvo_ctx *ctx, const RoiDev *rois, int n_roi, const
 // order, same greedy pass).  Outputs are device arrays [n_frames][cap]; the call returns once they are complete.
 // before_candidates, if given, is called right before the candidates launch is queued on the context's stream, once the
 // work area is set up (the detect-and-build entry point queues the pyramid build on the side stream there).
+// behind_detection, if given, is called once the route that needs no word from the device has queued everything, before
+// the host waits to learn whether that route stands: what it queues on the context's stream (the LK launch that reads
+// the corners) starts the moment the detection ends instead of a host round trip later.  *done_again tells the caller
+// that the route did not stand and the outputs were written a second time, behind whatever the hook queued.
 static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi &roi, const ktlvo_gftt_params *p,
-                             float *d_xy, float *d_resp, int *d_counts, int cap, const std::function<int()> &before_candidates = nullptr) {
+                             float *d_xy, float *d_resp, int *d_counts, int cap, const std::function<int()> &before_candidates = nullptr,
+                             const std::function<int()> &behind_detection = nullptr, bool *done_again = nullptr) {
     const size_t area = (size_t)roi.w * roi.h;
     if (area * (size_t)n_frames > 0x7fffffff) return KTLVO_ERR_CAPACITY; // candidate offsets are 32-bit
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -361,8 +366,18 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         }
         KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
         KTLVO_HIP(ctx, hipMemcpyAsync(h_many, d_many, 4, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (behind_detection) {
+            // wait for the two flags only, not for what the hook queues behind them
+            if (!ctx->ev_flags) KTLVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming));
+            KTLVO_HIP(ctx, hipEventRecord(ctx->ev_flags, ctx->stream));
+            rc = behind_detection();
+            if (rc != KTLVO_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+            KTLVO_HIP(ctx, hipEventSynchronize(ctx->ev_flags));
+        } else {
+            KTLVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
         if (!*h_many) return KTLVO_OK;
+        if (done_again) *done_again = true;
     }
 
     // Global path: the sort runs in global memory over the batch's largest candidate count, which the host fetches first.
@@ -591,6 +606,71 @@ extern "C" int ktlvo_detect_build_frames_dev(ktlvo_ctx *ctx, const int *detect_s
     // (also after a failed detection: the planes are being written)
     if (forked) KTLVO_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
     return rc != KTLVO_OK ? rc : frames_overflow_check(ctx, n_frames);
+}
+
+// The frame-pair stream's whole step in one call: corners of every pair's first frame, the pyramids, and the LK launch
+// that tracks the corners into the pairs' second frames.  Made as two calls (ktlvo_detect_build_frames_dev, then
+// ktlvo_pyrlk_batch_dev) the LK launch is queued only after the host has waited for the detection's flags, and the
+// device idles for that round trip (about 50 us of a 3.3 ms step); here it is queued behind the detection before the
+// host waits.  Results are those of the two calls; if the detection has to be done again by its other route (a frame
+// with more corners above the threshold than the sort in LDS holds), the LK launch is done again as well.
+extern "C" int ktlvo_detect_build_track_dev(ktlvo_ctx *ctx, const int *prev_slots, const int *next_slots, int n_pairs,
+                                            const ktlvo_roi *roi_in, const ktlvo_gftt_params *p, float *d_xy, float *d_response,
+                                            int *d_counts, int cap, const int *build_slots, int n_build, float *d_next_xy,
+                                            uint8_t *d_status, float *d_err, const ktlvo_lk_params *lk) {
+    if (!ctx || !p || !lk || n_pairs < 0 || (n_pairs > 0 && (!prev_slots || !next_slots)) || n_build < 0 ||
+        (n_build > 0 && !build_slots))
+        return KTLVO_ERR_INVALID;
+    KTLVO_BIND(ctx);
+    if (n_pairs == 0) return n_build ? ktlvo_build_pyramids(ctx, build_slots, n_build, lk->max_level, lk->win) : KTLVO_OK;
+    if (!d_xy || !d_response || !d_counts || !d_next_xy || !d_status || !d_err) return KTLVO_ERR_INVALID;
+    if (n_pairs > ctx->cfg.max_batch_pairs || cap > ctx->cfg.max_points) return KTLVO_ERR_CAPACITY;
+    ktlvo_roi roi;
+    int rc = frames_args_ok(ctx, prev_slots, n_pairs, roi_in, p, cap, roi);
+    if (rc != KTLVO_OK) return rc;
+    if (lk->max_level < 0) return KTLVO_ERR_INVALID;
+    if (lk->win != ctx->cfg.win) return KTLVO_ERR_UNSUPPORTED;
+    for (int i = 0; i < n_pairs; i++) {
+        if (!slot_ok(ctx, next_slots[i])) return KTLVO_ERR_INVALID;
+        if (ctx->built[next_slots[i]] < 0) return KTLVO_ERR_STATE;
+    }
+    for (int i = 0; i < n_build; i++) {
+        if (!slot_ok(ctx, build_slots[i])) return KTLVO_ERR_INVALID;
+        if (ctx->built[build_slots[i]] < 0) return KTLVO_ERR_STATE;
+    }
+    rc = device_streams(ctx);
+    if (rc != KTLVO_OK) return rc;
+    hipStream_t const main_stream = ctx->stream;
+    bool forked = false, joined = false, tracked = false, again = false;
+    auto build_on_side_stream = [&]() -> int {
+        if (n_build == 0) return KTLVO_OK;
+        KTLVO_HIP(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+        KTLVO_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->side_stream;
+        const int rb = ktlvo_build_pyramids(ctx, build_slots, n_build, lk->max_level, lk->win);
+        ctx->stream = main_stream;
+        if (rb != KTLVO_OK) return rb;
+        KTLVO_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+        forked = true;
+        return KTLVO_OK;
+    };
+    auto track = [&]() -> int {
+        if (forked && !joined) {
+            KTLVO_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+            joined = true;
+        }
+        tracked = true;
+        return ktlvo_pyrlk_batch_dev(ctx, prev_slots, next_slots, n_pairs, d_xy, cap, d_next_xy, d_status, d_err, lk);
+    };
+    rc = detect_frames_dev(ctx, prev_slots, n_pairs, roi, p, d_xy, d_response, d_counts, cap, build_on_side_stream, track, &again);
+    if (forked && !joined) { // (also after a failed detection: the planes are being written)
+        KTLVO_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        joined = true;
+    }
+    if (rc != KTLVO_OK) return rc;
+    rc = frames_overflow_check(ctx, n_pairs);
+    if (rc != KTLVO_OK) return rc;
+    return tracked && !again ? KTLVO_OK : track();
 }
 
 extern "C" int ktlvo_detect_gftt_frames(ktlvo_ctx *ctx, const int *slots, int n_frames, const ktlvo_roi *roi_in,

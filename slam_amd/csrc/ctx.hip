@@ -267,6 +267,7 @@ extern "C" void ktlvo_destroy(ktlvo_ctx *ctx) {
     release_device_streams(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_flags) (void)hipEventDestroy(ctx->ev_flags);
     for (int i = 0; i < 4; i++) if (ctx->d_pts[i]) (void)hipFree(ctx->d_pts[i]);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_err) (void)hipFree(ctx->d_err);

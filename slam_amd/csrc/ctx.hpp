@@ -81,6 +81,7 @@ struct ktlvo_ctx {
     hipStream_t copy_stream = nullptr; // host-to-device DMA of ktlvo_upload_images
     hipStream_t side_stream = nullptr; // the pyramid build of ktlvo_detect_build_frames_dev, beside the detection
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // this context's fences between its stream and the side stream
+    hipEvent_t ev_flags = nullptr;                   // behind the batched detection's two flags (the host waits for these, not for the stream)
     bool holds_device_streams = false;
     std::string last_error;
 

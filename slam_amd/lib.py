@@ -99,6 +99,8 @@ SIGNATURES = {
     "ktlvo_detect_gftt_frames": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_detect_gftt_frames_dev": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_detect_build_frames_dev": (_i, [_vp, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i, _ip, _i, _i, _i]),
+    "ktlvo_detect_build_track_dev": (_i, [_vp, _ip, _ip, _i, C.POINTER(Roi), C.POINTER(GfttParams), _vp, _vp, _vp, _i, _ip, _i, _vp, _vp,
+                                          _vp, C.POINTER(LkParams)]),
     "ktlvo_detect_gftt_noalloc": (_i, [_vp, _i, C.POINTER(Roi), _i, C.POINTER(GfttParams), _vp, _vp, _vp, _i]),
     "ktlvo_corner_response": (_i, [_vp, _i, C.POINTER(Roi), _i, _d, _vp]),
     "ktlvo_anms": (_i, [_vp, _vp, _vp, _ip, _i]),
@@ -374,6 +376,18 @@ class Context:
         self._chk(lib.ktlvo_detect_build_frames_dev(self._h, arr, n, r, C.byref(params), d_xy, d_resp, d_counts, cap, barr, nb,
                                                     self.cfg.max_level if max_level is None else max_level,
                                                     self.cfg.win if win is None else win), "ktlvo_detect_build_frames_dev")
+
+    def detect_build_track_dev(self, prev_slots, next_slots, params, d_xy, d_resp, d_counts, cap, build_slots, d_next, d_status,
+                               d_err, lk, roi=None):
+        """The frame-pair stream's step in one call: detect_build_frames_dev(prev_slots, ..., build_slots) and
+        pyrlk_batch_dev(prev_slots, next_slots, d_xy, cap, ...), the LK launch queued behind the detection."""
+        n, nb = len(prev_slots), len(build_slots)
+        assert len(next_slots) == n
+        pa, na = (C.c_int * max(n, 1))(*prev_slots), (C.c_int * max(n, 1))(*next_slots)
+        barr = (C.c_int * max(nb, 1))(*build_slots)
+        r = C.byref(Roi(*roi)) if roi is not None else None
+        self._chk(lib.ktlvo_detect_build_track_dev(self._h, pa, na, n, r, C.byref(params), d_xy, d_resp, d_counts, cap, barr, nb,
+                                                   d_next, d_status, d_err, C.byref(lk)), "ktlvo_detect_build_track_dev")
 
     def detect_gftt_noalloc(self, slot, rois, params, d_xy, d_resp, d_counts, cap):
         """Device-pointer form that allocates nothing; returns the status code (no exception) so that tests

@@ -860,6 +860,76 @@ def test_detect_and_build_side_by_side_equals_calls_in_turn(make_ctx, klib):
     assert c.pyramid_levels(0) == 0                                           # nothing was built by the refused calls
 
 
+def test_stream_step_in_one_call_equals_the_two_calls(make_ctx, klib):
+    """ktlvo_detect_build_track_dev (detection, pyramid build and the LK launch queued in one go, the host waiting for the
+    detection's flags only) against ktlvo_detect_build_frames_dev followed by ktlvo_pyrlk_batch_dev: same corners, counts,
+    tracks, status and error bits.  Two rounds on textured frames (the route queued blind stands), then a round with a
+    noise frame whose corners exceed what the sort in LDS holds (the detection is done again by the other route, and so
+    is the LK launch), then the empty forms and a refusal."""
+    import torch
+    W, H, n, cap = 640, 360, 11, 600   # more than 8 frames: a workgroup per frame sorts in LDS (16384 keys at most)
+    a, b = make_ctx(width=W, height=H, num_slots=n), make_ctx(width=W, height=H, num_slots=n)
+    params = klib.gftt_params(cap, 0.01, 7.0, 3, 0, 0.0)
+    lk = klib.lk_params()
+    prev, nxt, slots = list(range(n - 1)), list(range(1, n)), list(range(n))
+    P = n - 1
+    rng = np.random.default_rng(5)
+    rounds = []
+    for rnd in range(3):
+        imgs = [synth.texture_image(W, H, 70 + 10 * rnd, dx=0.8 * s, dy=-0.3 * s, noise=True) for s in range(n)]
+        if rnd == 2:
+            imgs[2] = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        rounds.append(np.stack(imgs))
+    out = {}
+    for tag, ctx in (("two", a), ("one", b)):
+        bufs = [torch.zeros((P, cap, 2), device="cuda"), torch.zeros((P, cap), device="cuda"),
+                torch.zeros(P, dtype=torch.int32, device="cuda"), torch.zeros((P, cap, 2), device="cuda"),
+                torch.zeros((P, cap), dtype=torch.uint8, device="cuda"), torch.zeros((P, cap), device="cuda")]
+        d_xy, d_r, d_c, d_n, d_s, d_e = [t.data_ptr() for t in bufs]
+        torch.cuda.synchronize()
+        res = []
+        for imgs in rounds:
+            ctx.upload_images(slots, imgs)
+            if tag == "two":
+                ctx.detect_build_frames_dev(prev, params, d_xy, d_r, d_c, cap, slots)
+                ctx.pyrlk_batch_dev(prev, nxt, d_xy, cap, d_n, d_s, d_e, lk)
+            else:
+                ctx.detect_build_track_dev(prev, nxt, params, d_xy, d_r, d_c, cap, slots, d_n, d_s, d_e, lk)
+            ctx.sync()
+            res.append([t.cpu().numpy().copy() for t in bufs])
+        out[tag] = res
+    for rnd in range(3):
+        t, o = out["two"][rnd], out["one"][rnd]
+        cnt = t[2]
+        assert np.array_equal(cnt, o[2]) and cnt.min() > 100
+        for f in range(P):
+            k = int(cnt[f])
+            for q in (0, 1, 3, 4, 5):
+                assert np.array_equal(t[q][f, :k], o[q][f, :k]), (rnd, f, q)
+    assert out["two"][2][2][2] == cap                                        # the noise frame fills its list
+    assert not np.array_equal(out["two"][0][3], out["two"][1][3])
+    # no pairs: the build alone; no pairs and nothing to build: nothing
+    bufs = [torch.zeros((2, cap, 2), device="cuda"), torch.zeros((2, cap), device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"),
+            torch.zeros((2, cap, 2), device="cuda"), torch.zeros((2, cap), dtype=torch.uint8, device="cuda"), torch.zeros((2, cap), device="cuda")]
+    d_xy, d_r, d_c, d_n, d_s, d_e = [t.data_ptr() for t in bufs]
+    b.detect_build_track_dev([], [], params, d_xy, d_r, d_c, cap, [0, 1], d_n, d_s, d_e, lk)
+    b.detect_build_track_dev([], [], params, d_xy, d_r, d_c, cap, [], d_n, d_s, d_e, lk)
+    # pairs without a build list: the pyramids of the last round are tracked on
+    b.detect_build_track_dev(prev[:2], nxt[:2], params, d_xy, d_r, d_c, cap, [], d_n, d_s, d_e, lk)
+    b.sync()
+    o = out["one"][2]
+    assert np.array_equal(bufs[2].cpu().numpy(), o[2][:2])
+    k = int(o[2][0])
+    assert np.array_equal(bufs[3].cpu().numpy()[0, :k], o[3][0, :k]) and np.array_equal(bufs[4].cpu().numpy()[0, :k], o[4][0, :k])
+    # a second frame without an image: refused before anything is queued
+    c = make_ctx(width=W, height=H, num_slots=3)
+    c.upload_image(0, synth.texture_image(W, H, 3))
+    with pytest.raises(klib.KtlvoError) as ei:
+        c.detect_build_track_dev([0], [1], params, d_xy, d_r, d_c, cap, [0], d_n, d_s, d_e, lk)
+    assert ei.value.status == klib.ERR_STATE
+    assert c.pyramid_levels(0) == 0
+
+
 def test_batched_detection_equals_per_frame_detection(make_ctx, klib):
     """ktlvo_detect_gftt_frames: the whole-frame detector over a batch of frames with the launches of one
     detection.  Every frame's corners, order and responses equal ktlvo_detect_gftt's for that frame: frames of

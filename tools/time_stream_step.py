@@ -2,7 +2,9 @@
 """The frame-pair stream's whole step (detect on the first frames, build all pyramids, track the detected corners) in
 its arrangements, on the benchmark's shape with fewer pairs if asked; run on a GPU box, alone for wall times or under
 `rocprofv3 --kernel-trace` for the kernels' timeline (tools/trace_timeline.py reads its CSV).
-usage: time_stream_step.py [pairs_per_sequence=127] [reps=10] [arrangement: turn|side|both]"""
+usage: time_stream_step.py [pairs_per_sequence=127] [reps=10] [arrangement: turn|side|one|both|pair]
+(one: ktlvo_detect_build_track_dev; both: the three single-context arrangements in turn)
+(pair: the side-by-side step on two contexts in turn, each with its own frames and arrays)"""
 import os
 import sys
 import time
@@ -38,6 +40,10 @@ torch.cuda.synchronize()
 
 
 def step(side):
+    if side == "one":
+        ctx.detect_build_track_dev(prev, nxt, gp, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), NF, slots, d_n.data_ptr(),
+                                   d_s.data_ptr(), d_e.data_ptr(), lk)
+        return
     if side:
         ctx.detect_build_frames_dev(prev, gp, d_xy.data_ptr(), d_r.data_ptr(), d_c.data_ptr(), NF, slots)
     else:
@@ -46,7 +52,30 @@ def step(side):
     ctx.pyrlk_batch_dev(prev, nxt, d_xy.data_ptr(), NF, d_n.data_ptr(), d_s.data_ptr(), d_e.data_ptr(), lk)
 
 
-for side in ([False, True] if which == "both" else [which == "side"]):
+if which == "pair":
+    ctx2 = K.Context(K.default_config(width=W, height=H, num_slots=NI, max_points=NF, cx=scene.cx, cy=scene.cy))
+    ctx2.upload_images(slots, np.stack(frames))
+    ctx2.sync()
+    bufs2 = [torch.zeros_like(t) for t in (d_xy, d_r, d_c, d_n, d_s, d_e)]
+    both = [(ctx, (d_xy, d_r, d_c, d_n, d_s, d_e)), (ctx2, bufs2)]
+
+    def pair_step(k):
+        c, (xy, r, cn, n_, s_, e_) = both[k & 1]
+        c.detect_build_frames_dev(prev, gp, xy.data_ptr(), r.data_ptr(), cn.data_ptr(), NF, slots)
+        c.pyrlk_batch_dev(prev, nxt, xy.data_ptr(), NF, n_.data_ptr(), s_.data_ptr(), e_.data_ptr(), lk)
+
+    for k in range(6):
+        pair_step(k)
+    ctx.sync(); ctx2.sync()
+    t = time.perf_counter()
+    for k in range(2 * reps):
+        pair_step(k)
+    ctx.sync(); ctx2.sync()
+    print("two contexts in turn: %.4f ms per step" % ((time.perf_counter() - t) / (2 * reps) * 1e3), flush=True)
+    ctx2.close()
+    ctx.close()
+    sys.exit(0)
+for side in ([False, True, "one"] if which == "both" else ["one"] if which == "one" else [which == "side"]):
     for _ in range(5):
         step(side)
     ctx.sync()
@@ -55,5 +84,5 @@ for side in ([False, True] if which == "both" else [which == "side"]):
         step(side)
     ctx.sync()
     dt = (time.perf_counter() - t) / reps
-    print("%s: %.4f ms per step" % ("side by side" if side else "in turn", dt * 1e3), flush=True)
+    print("%s: %.4f ms per step" % ("one call" if side == "one" else "side by side" if side else "in turn", dt * 1e3), flush=True)
 ctx.close()
