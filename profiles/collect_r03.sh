@@ -34,7 +34,9 @@ timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/det
 timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/frame_path -- python3 $R/tools/time_frame_path.py 40 > $O/frame_path.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/stream_side -- python3 $R/tools/time_stream_step.py 127 4 side > $O/stream_side.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/stream_turn -- python3 $R/tools/time_stream_step.py 127 4 turn > $O/stream_turn.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/stream_one -- python3 $R/tools/time_stream_step.py 127 4 one > $O/stream_one.log 2>&1
 cd $R
+python3 tools/trace_timeline.py $(ls $O/stream_one/*/*kernel_trace.csv | head -1) 17 > $O/stream_one_timeline.txt
 python3 tools/trace_timeline.py $(ls $O/stream_side/*/*kernel_trace.csv | head -1) 17 > $O/stream_side_timeline.txt
 python3 tools/trace_timeline.py $(ls $O/stream_turn/*/*kernel_trace.csv | head -1) 17 > $O/stream_turn_timeline.txt
 python3 profiles/summarize_pmc.py $O/pmc_summary.json $(find $O/pmc_* -name "*counter_collection.csv") > $O/summary.log
