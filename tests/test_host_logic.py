@@ -218,3 +218,6 @@ def test_bench_cpu_baseline_leg_runs_on_the_host():
     assert out["kind"] == "port" and out["value"] > 0 and out["cores"] >= 1
     assert len(out["lk_iterations_per_level_mean"]) >= 3 and out["single_thread"]["value"] > 0
     assert out["four_accumulators"]["value"] > 0 and out["all_cores_over_one_thread"] > 0 and "-O3" in out["build"]
+    assert out["pairs_in_parallel"]["value"] > 0 and out["pairs_in_parallel_over_one_thread"] > 0
+    assert out["value"] == max(out["pairs_in_parallel"]["value"], out["stripes_within_a_pair"]["value"])
+    assert out["arrangement"] in ("pairs_in_parallel", "stripes_within_a_pair")
