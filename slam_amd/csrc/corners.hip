@@ -333,9 +333,13 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
         if (rc != KTLVO_OK) return rc;
         char *b = (char *)ctx->d_aux;
         unsigned long long *d_keys = (unsigned long long *)b;
-        int *d_n = (int *)(b + o_n), *d_many = (int *)(b + o_flag);
-        KTLVO_HIP(ctx, hipMemsetAsync(b + o_flag, 0, o_cp - o_flag, ctx->stream)); // the flag and, if used, the cells' counts
-        if (global_grid) KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+        // the "do it again" flag: the work area's second flag, which the set-up kernel has cleared (no memset, and it
+        // comes home with the overflow flag in one copy); only a grid in global memory needs clearing here
+        int *d_n = (int *)(b + o_n), *d_many = s.d_overflow + 1;
+        if (global_grid) {
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_cc, 0, o_cp - o_cc, ctx->stream));
+            KTLVO_HIP(ctx, hipMemsetAsync(b + o_cp, 0xFF, cells * 16 * n_frames, ctx->stream));
+        }
         if (few) {
             bool sorted;
             KTLVO_HIP(ctx, hipMemsetAsync(b + o_zero, 0, total - o_zero, ctx->stream));
@@ -364,8 +368,7 @@ static int detect_frames_dev(ktlvo_ctx *ctx, const int *slots, int n_frames, con
             }
             if (rc != KTLVO_OK) return rc;
         }
-        KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-        KTLVO_HIP(ctx, hipMemcpyAsync(h_many, d_many, 4, hipMemcpyDeviceToHost, ctx->stream));
+        KTLVO_HIP(ctx, hipMemcpyAsync(h_ovf, s.d_overflow, 8, hipMemcpyDeviceToHost, ctx->stream)); // (the second lands on h_many)
         if (behind_detection) {
             // wait for the two flags only, not for what the hook queues behind them
             if (!ctx->ev_flags) KTLVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_flags, hipEventDisableTiming));
