@@ -14,6 +14,24 @@ constexpr int CI = CT + 6; // image tile (3-pixel frame)
 constexpr int CC = CT + 4; // covariance tile (2-pixel frame)
 constexpr int CR = CT + 2; // response tile with its 1-pixel frame for the local-maximum test
 
+// sqrtf (correctly rounded) for the minimum-eigenvalue response's radicand (ha - hc)^2 + fb^2, which is zero or lies in
+// [2^-104, 1): the sums behind it are nine products of at least 2^-28 each or zero, so a difference of two of them is a
+// multiple of 2^-52 and a non-zero radicand is at least 2^-104.  The hardware root is within one ulp; the two residuals
+// x - s (s -/+ 1 ulp), one fused operation each, tell which neighbour is the rounded root (the compiler's own expansion
+// of sqrtf).  That expansion also tests for tiny radicands, whose residuals would be subnormal, and scales those;
+// scaling every radicand by 2^64 (the root by 2^-32, both exact here) needs no test and no special case for zero, which
+// keeps its value through the not-a-number and subnormal neighbours the bit arithmetic gives it: 11 instructions
+// instead of 16.
+__device__ __forceinline__ float sqrt_rn_radicand(float x) {
+    const float xs = x * 0x1p+64f;
+    float s = __builtin_amdgcn_sqrtf(xs);
+    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float rd = __builtin_fmaf(-dn, s, xs), ru = __builtin_fmaf(-up, s, xs);
+    s = rd <= 0.f ? dn : s;
+    s = ru > 0.f ? up : s;
+    return s * 0x1p-32f;
+}
+
 __device__ __forceinline__ int reflect101d(int p, int n) {
     if (n == 1) return 0;
     while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
@@ -162,7 +180,7 @@ __global__ __launch_bounds__(256) void corner_candidates(const SlotDesc *slots, 
                         r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
                     } else {
                         const float ha = fa * 0.5f, hc = fc * 0.5f;
-                        r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
+                        r = (ha + hc) - sqrt_rn_radicand((ha - hc) * (ha - hc) + fb * fb);
                     }
                     if (px >= 1 && py >= 1 && px <= CT && py <= CT) { // this workgroup's own pixels
                         vmax = fmaxf(vmax, r);
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
             r = (float)((double)t - k * (double)(fa + fc) * (double)(fa + fc));
         } else {
             const float ha = fa * 0.5f, hc = fc * 0.5f;
-            r = (ha + hc) - sqrtf((ha - hc) * (ha - hc) + fb * fb);
+            r = (ha + hc) - sqrt_rn_radicand((ha - hc) * (ha - hc) + fb * fb);
         }
         if (lane >= 2 && lane <= 61 && in_cols) vmax = fmaxf(vmax, r);
         if (resp_out && own && yr >= y0 && yr < y1) resp_out[R.off + yr * W + x] = r;
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(256) void corner_candidates_wave(const SlotDesc *sl
         if (!cand || yo < y0 || yo < 1 || yo >= H - 1) return;
         const float m = fmaxf(fmaxf(mA, mB), mC);
         const bool keep = cand_col && vB > 0.f && vB == m;
-        const unsigned long long vote = __ballot(keep);
+        const unsigned long long vote = __builtin_amdgcn_ballot_w64(keep);
         if (vote) {
             if (keep) buf[n_buf + __popcll(vote & ((1ull << lane) - 1ull))] = ((unsigned long long)f2ord(vB) << 32) | (unsigned)((yo << 16) | x);
             n_buf += __popcll(vote);
