@@ -42,6 +42,7 @@ DTYPE = {0: "u8 -> i32 fixed point, exact i64-equivalent window sums rounded onc
          2: "u8 -> i32 fixed point, exact i64-equivalent window sums rounded once to f32",
          1: "u8 -> i32 fixed point, f32 window sums in a fixed 64-lane tree"}
 
+STREAM_STEPS = 40   # steps of the host-fed legs' timed regions (amortise the one upload that nothing hides)
 PREWARM_STEPS = 40  # untimed steps before the warm-up proper (clock run-up after the host-side set-up)
 
 
@@ -717,13 +718,16 @@ def main():
                     ctx.upload_images(slots, upload)
                 full_step(side_by_side)
             ctx.sync()
+            # fed from the host the timed region starts with an empty pipeline: its first upload (2.1 ms) runs under
+            # nothing, which only many steps amortise (40 steps: 0.05 ms per step; 10 steps would add 0.2 ms to each)
+            n = reps if upload is None else max(reps, STREAM_STEPS)
             t = time.perf_counter()
-            for _ in range(reps):
+            for _ in range(n):
                 if upload is not None:
                     ctx.upload_images(slots, upload)
                 full_step(side_by_side)
             ctx.sync()
-            return (time.perf_counter() - t) / reps
+            return (time.perf_counter() - t) / n
 
         reps = max(5, a.steps // 2)
         t_full = timed_full(False)
@@ -798,7 +802,9 @@ def main():
                 c.sync()
 
         def timed_stream(n_ctx, wait, n):
-            for k in range(4):
+            # the run-up has to bring the clocks back up after the arrangement before it (waiting for every upload leaves
+            # the device idle half of the time, and the launches after such a spell run up to 20 % longer for some 30 ms)
+            for k in range(4 if wait else PREWARM_STEPS):
                 stream_step(k, n_ctx, wait)
             for c in two:
                 c.sync()
@@ -817,7 +823,7 @@ def main():
             two[0].sync()
             return (time.perf_counter() - t) / n
 
-        n_s = max(6, a.steps)
+        n_s = max(STREAM_STEPS, a.steps)   # (the timed region's first upload is not hidden: see timed_full)
         t_dma = timed_dma(n_s)
         t_serial = timed_stream(1, True, n_s)
         t_one = timed_stream(1, False, n_s)
