@@ -227,6 +227,58 @@ def run_sequence(a, rank, world, local, dev):
         assert np.array_equal(all_poses[i], all_poses[0]) and stats[i][1] == stats[0][1], "instance %d differs" % i
     poses = all_poses[0]
     ate2, tracked, keyframes, gt = stats[0]
+    # The reference runs the two halves as two processes (vo.launch:3-5: feature_tracking_node publishes the clouds,
+    # visual_odometry_node estimates the pose), so frame N+1 is tracked while frame N's pose is estimated.  The same here
+    # with two host threads and a context each (ktlvo_track_stereo_frame on one, ktlvo_estimate_pose on the other, the
+    # clouds handed over through a queue); the poses must be those of the run above, bit for bit.
+    two_nodes = None
+    if S == 1 and world == 1:
+        import queue
+        import threading
+        cfg2 = K.default_config(width=W, height=H, cx=scene.cx, cy=scene.cy)
+        ctx_t, ctx_p = K.Context(cfg2, device=local), K.Context(cfg2, device=local)
+        poses2 = np.zeros_like(poses)
+        poses2[0] = np.eye(4, dtype=np.float32).reshape(16)
+        clouds = queue.Queue(maxsize=4)
+        failed = []
+
+        def tracking_node():
+            try:
+                for f, (L, R) in enumerate(frames):
+                    last, cur, _ = ctx_t.track_stereo_frame(L, R)
+                    if f:
+                        clouds.put((f, last, cur))
+            except Exception as e:      # the other node must not wait for ever
+                failed.append(e)
+            clouds.put(None)
+
+        def odometry_node():
+            try:
+                while True:
+                    item = clouds.get()
+                    if item is None:
+                        return
+                    f, last, cur = item
+                    poses2[f] = ctx_p.estimate_pose(last, cur)[2].reshape(16)
+            except Exception as e:
+                failed.append(e)
+                while clouds.get() is not None:
+                    pass
+
+        ctx_t.sync(); ctx_p.sync()
+        t1 = time.perf_counter()
+        nodes = [threading.Thread(target=tracking_node), threading.Thread(target=odometry_node)]
+        for t in nodes:
+            t.start()
+        for t in nodes:
+            t.join()
+        t_two = time.perf_counter() - t1
+        assert not failed, failed
+        assert np.array_equal(poses2, poses), "the two-node run's poses differ"
+        two_nodes = {"value": a.frames / t_two, "unit": "frames/s", "ms_per_frame": t_two / a.frames * 1e3,
+                     "note": "tracking and pose estimation on two host threads with a context each, as the reference's two "
+                             "nodes run them; poses identical to the single-thread run"}
+        ctx_t.close(); ctx_p.close()
     t_max = shard.max_over_ranks(elapsed, dev, world)
     traj = shard.gather_trajectories(torch.from_numpy(poses).to(dev), world)
     rec = torch.tensor([float(a.frames), float(tracked), float(keyframes), np.sqrt(ate2 / max(a.frames - 1, 1)),
@@ -243,6 +295,7 @@ def run_sequence(a, rank, world, local, dev):
             "per_rank": [{"tracked_points": r[1], "key_frames": r[2], "ate_rmse_m": r[3], "path_m": r[4],
                           "elapsed_s": r[5]} for r in recs.tolist()],
             "trajectory_shape": list(traj.shape),
+            "two_nodes": two_nodes,
             "note": "per frame: 2 host->device uploads (pinned staging), 1 pyramid + Scharr build for the two new "
                     "images, ONE LK launch for the reference's 8 calls (six tracks per point as two chains), one gate kernel, "
                     "RANSAC pose with one scoring launch"}))
