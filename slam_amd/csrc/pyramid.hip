@@ -36,8 +36,16 @@ __device__ __forceinline__ void ingest_16(const LevelDesc &L, const uint8_t *src
         return;
     }
     uint32_t v[4] = {0, 0, 0, 0};
+    if (L.w > PAD) { // one reflection reaches every column of the frame: no loop per byte
 #pragma unroll
-    for (int k = 0; k < 16; k++) v[k >> 2] |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * (k & 3));
+        for (int k = 0; k < 16; k++) {
+            const int c = x + k, m = c < 0 ? -c : c >= L.w ? 2 * L.w - 2 - c : c;
+            v[k >> 2] |= (uint32_t)row[m] << (8 * (k & 3));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k >> 2] |= (uint32_t)row[reflect101(x + k, L.w)] << (8 * (k & 3));
+    }
     if (x + 15 < L.w + PAD) {
         *(__attribute__((address_space(1))) u32x4 *)out = u32x4{v[0], v[1], v[2], v[3]};
     } else { // the plane's rows end at w + PAD: what lies beyond stays as it is
