@@ -1,6 +1,7 @@
 // Corner response, ROI maximum and local-maximum test of cv::goodFeaturesToTrack in one pass over the image
 // (featureTracking.cpp:102-103, 421-422), and the set-up of the detector's work area.  See corners.hpp.
 #include "corners.hpp"
+#include "sqrt_rn.hpp"
 
 #include <cstring>
 
@@ -13,24 +14,6 @@ constexpr int CT = 32;     // response tile owned by a workgroup
 constexpr int CI = CT + 6; // image tile (3-pixel frame)
 constexpr int CC = CT + 4; // covariance tile (2-pixel frame)
 constexpr int CR = CT + 2; // response tile with its 1-pixel frame for the local-maximum test
-
-// sqrtf (correctly rounded) for the minimum-eigenvalue response's radicand (ha - hc)^2 + fb^2, which is zero or lies in
-// [2^-104, 1): the sums behind it are nine products of at least 2^-28 each or zero, so a difference of two of them is a
-// multiple of 2^-52 and a non-zero radicand is at least 2^-104.  The hardware root is within one ulp; the two residuals
-// x - s (s -/+ 1 ulp), one fused operation each, tell which neighbour is the rounded root (the compiler's own expansion
-// of sqrtf).  That expansion also tests for tiny radicands, whose residuals would be subnormal, and scales those;
-// scaling every radicand by 2^64 (the root by 2^-32, both exact here) needs no test and no special case for zero, which
-// keeps its value through the not-a-number and subnormal neighbours the bit arithmetic gives it: 11 instructions
-// instead of 16.
-__device__ __forceinline__ float sqrt_rn_radicand(float x) {
-    const float xs = x * 0x1p+64f;
-    float s = __builtin_amdgcn_sqrtf(xs);
-    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
-    const float rd = __builtin_fmaf(-dn, s, xs), ru = __builtin_fmaf(-up, s, xs);
-    s = rd <= 0.f ? dn : s;
-    s = ru > 0.f ? up : s;
-    return s * 0x1p-32f;
-}
 
 __device__ __forceinline__ int reflect101d(int p, int n) {
     if (n == 1) return 0;
