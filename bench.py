@@ -74,7 +74,7 @@ def source_sha1(rel):
         return None
 
 
-def measured_traffic(kernel, waves_per_launch, source="slam_amd/csrc/pyrlk.hip"):
+def measured_traffic(kernel, waves_per_launch, source="slam_amd/csrc/pyrlk.hip", suffix=""):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary
     (profiles/r*_pmc_summary.json, written by profiles/summarize_pmc.py from separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command, gfx950 FETCH_SIZE
@@ -83,7 +83,8 @@ def measured_traffic(kernel, waves_per_launch, source="slam_amd/csrc/pyrlk.hip")
     matches this launch shape and source."""
     import glob
     sha = source_sha1(source)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+    # (suffix: "_exact_sums" for the counters collected with --lk-sums exact; the plain files are the default reading's)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % suffix)), reverse=True):
         try:
             doc = json.load(open(path))
         except (OSError, ValueError):
@@ -142,8 +143,8 @@ def parse():
                     help="kernels bracketed by HIP events inside the timed region: the dominant one (default; the "
                          "pyramid kernels are then timed in an untimed pass) or all three")
     ap.add_argument("--lk-sums", choices=["default", "exact", "tree"], default="default",
-                    help="rounding of LK's window sums (ktlvo_lk_params.sums): the library's default (exact integer "
-                         "totals rounded once), or the float tree")
+                    help="rounding of LK's window sums (ktlvo_lk_params.sums): the library's default (the float tree), "
+                         "exact integer totals rounded once, or the float tree by name")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED0002)
     ap.add_argument("--workload", choices=["pairs", "sequence", "ransac", "batch"], default="pairs",
                     help="pairs: the headline frame-pair stream (default); sequence: stereo tracker + pose on a "
@@ -168,7 +169,8 @@ def parse():
     if a.height is None: a.height = shape[1]
     if a.features is None: a.features = shape[2]
     if a.min_dist is None: a.min_dist = shape[3]
-    a.lk_sums = {"default": K.LK_SUMS_DEFAULT, "exact": K.LK_SUMS_EXACT, "tree": K.LK_SUMS_TREE}[a.lk_sums]
+    # "default" is whatever the library's default configuration says (the float tree)
+    a.lk_sums = {"default": K.default_config().lk_sums, "exact": K.LK_SUMS_EXACT, "tree": K.LK_SUMS_TREE}[a.lk_sums]
     return a
 
 
@@ -975,7 +977,8 @@ def main():
         for _ in range(levels):
             lv_bytes += w_ * h_
             w_, h_ = (w_ + 1) // 2, (h_ + 1) // 2
-        traffic, traffic_src, pmc = measured_traffic("pyrlk_track_w21", feats_per_launch)
+        traffic, traffic_src, pmc = measured_traffic("pyrlk_track_w21", feats_per_launch,
+                                                     suffix="_exact_sums" if a.lk_sums == K.LK_SUMS_EXACT else "")
         # What the kernel is really limited by: vector-ALU issue.  The ceiling is MEASURED (tools/probe/issue_rate.hip):
         # on gfx950 a SIMD issues v_fma_f32 / v_add_f32 every 2.2 cycles but integer, permute, dot2-i16, DPP,
         # convert and packed-f32 instructions every 4.2; the LK step's own mix costs 3.9 cycles per

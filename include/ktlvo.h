@@ -65,18 +65,20 @@ typedef struct {
                                       solvePnPRansac); 1: solved by a HIP kernel, one thread per hypothesis
                                       (same algorithm, device libm: poses agree to ~1e-12) */
     int lk_sums;                   /* how calcOpticalFlowPyrLK's five window sums per level are rounded when a call's
-                                      ktlvo_lk_params.sums is KTLVO_LK_SUMS_DEFAULT: KTLVO_LK_SUMS_EXACT or _TREE */
+                                      ktlvo_lk_params.sums is KTLVO_LK_SUMS_DEFAULT: KTLVO_LK_SUMS_TREE (the default,
+                                      also for 0) or KTLVO_LK_SUMS_EXACT */
     int p3p_polish;                /* Newton steps on the roots of the P3P quartic: 0 = none, the closed-form
                                       roots of OpenCV 3's p3p.cpp as visualOdometry.cpp:206-208 reaches it */
 } ktlvo_config;
 
 /* The float accumulators of LKTrackerInvoker (A11, A12, A22, b1, b2: 441 integer-valued terms each) depend on
  * the order of addition, which no parallel implementation shares with a serial one.
+ *   KTLVO_LK_SUMS_TREE (the default): per-lane integer partials added as floats in a fixed 64-lane tree;
+ *     deterministic, within float rounding of any other order of addition, OpenCV's serial one included.
  *   KTLVO_LK_SUMS_EXACT: every sum is the exact integer total of its terms, rounded to float once (to nearest
  *     even).  Order-independent, so any implementation that sums exactly reproduces positions, status and
- *     error bit for bit.
- *   KTLVO_LK_SUMS_TREE: per-lane integer partials added as floats in a fixed 64-lane tree (four vector
- *     instructions fewer per Gauss-Newton step); deterministic, within float rounding of any other order. */
+ *     error bit for bit (the CPU oracle's matching mode does); four vector instructions more per Gauss-Newton
+ *     step, 5 to 6 % of a large launch's time. */
 enum { KTLVO_LK_SUMS_DEFAULT = 0, KTLVO_LK_SUMS_TREE = 1, KTLVO_LK_SUMS_EXACT = 2 };
 
 /* cv::calcOpticalFlowPyrLK arguments as passed at featureTracking.cpp:205-209. */

@@ -150,7 +150,7 @@ extern "C" int ktlvo_default_config(ktlvo_config *c) {
     c->ransac_reproj = 0.1f;
     c->ransac_conf = (double)0.99f;
     c->max_hypotheses = 1024;
-    c->lk_sums = KTLVO_LK_SUMS_EXACT;
+    c->lk_sums = KTLVO_LK_SUMS_TREE;
     c->p3p_polish = 0;
     return KTLVO_OK;
 }

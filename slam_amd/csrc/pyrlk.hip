@@ -806,7 +806,7 @@ static void set_criteria(Args &a, const ktlvo_lk_params *p, int max_level) {
 // Which reading of the window sums a call asks for: its own setting, else the context's.
 static bool exact_sums(const ktlvo_ctx *ctx, const ktlvo_lk_params *p) {
     const int m = p->sums != KTLVO_LK_SUMS_DEFAULT ? p->sums : ctx->cfg.lk_sums;
-    return m != KTLVO_LK_SUMS_TREE;
+    return m == KTLVO_LK_SUMS_EXACT;
 }
 
 // d_out: B, C, D, E, CHK, CHKB as in pyrlk_frame_chain, n points each.  Returns KTLVO_ERR_UNSUPPORTED when the four

@@ -201,6 +201,7 @@ int main(int argc, char **argv) {
         ktlvo_default_config(&cfg);
         cfg.width = W;
         cfg.height = H;
+        cfg.lk_sums = KTLVO_LK_SUMS_EXACT; // the order-independent reading of LK's window sums: comparable with the oracle bit for bit
         Frontend feA(&cfg), feB(&cfg), feE(&cfg);
         check_error_behaviour(feE, frames.data(), W, H);
 
@@ -209,7 +210,7 @@ int main(int argc, char **argv) {
         orc_default_config(&oc);
         oc.width = W; oc.height = H; oc.nthreads = 8;
         orc_tracker *otr = with_oracle ? orc_tracker_create(&oc) : nullptr;
-        orc_set_lk_sum_mode(3); // exact window sums, the library's default reading: the clouds must then be the same bytes
+        orc_set_lk_sum_mode(3); // exact window sums on both sides: the clouds must then be the same bytes
         std::vector<orc_depth_point> oLast(cfg.max_points);
         std::vector<orc_image_point> oCur(cfg.max_points);
 

@@ -53,7 +53,7 @@ def test_pyramid_scharr_lk_random_sizes(make_ctx, oracle, klib):
         pts = np.stack([rng.uniform(-30, w + 30, n), rng.uniform(-30, h + 30, n)], 1).astype(np.float32)
         pts[:8] = [[0, 0], [w - 1, h - 1], [w, h], [-21, -21], [w - 0.5, 0.25], [0.25, h - 0.5], [w / 2, h / 2],
                    [10.5, 10.5]]
-        # exact window sums (the default): the same bits as the oracle summing exactly, on every kind of frame -- white
+        # exact window sums (the contexts of these tests ask for them): the same bits as the oracle summing exactly, on every kind of frame -- white
         # noise, where LK runs into its iteration limit and any difference in a sum's last bit grows over up to 150
         # steps, included
         go, gs, ge = ctx.pyrlk(0, 1, pts)

@@ -2,10 +2,10 @@
 the CPU oracle on the same seeded inputs and with the committed golden vectors.
 
 Bars: bit-exact for integer/byte/index work (pyramid, Scharr, corner sets, gates, inlier
-counts).  LK has two readings of its five window sums per level.  With exact sums (the library's
-default: integer totals rounded to float once, KTLVO_LK_SUMS_EXACT) positions, status flags and
+counts).  LK has two readings of its five window sums per level.  With exact sums (integer totals
+rounded to float once, KTLVO_LK_SUMS_EXACT: what make_ctx asks for unless a test says otherwise) positions, status flags and
 errors are BIT-EQUAL to the oracle summing the same way, whatever the image.  With the float tree
-(KTLVO_LK_SUMS_TREE) against the oracle's serial float accumulator (OpenCV's scalar order) the
+(KTLVO_LK_SUMS_TREE, the library's default) against the oracle's serial float accumulator (OpenCV's scalar order) the
 bars are the task statement's: positions within 0.05 px, >= 99.5 % identical status flags."""
 import os
 
@@ -153,7 +153,7 @@ def test_lk_matches_oracle_and_truth(make_ctx, oracle, klib, shift):
     ctx.build_pyramids([0, 1])
     rng = np.random.default_rng(0)
     pts = np.stack([rng.uniform(-5, W + 5, 3000), rng.uniform(-5, H + 5, 3000)], 1).astype(np.float32)
-    assert ctx.cfg.lk_sums == klib.LK_SUMS_EXACT      # the default reading
+    assert ctx.cfg.lk_sums == klib.LK_SUMS_EXACT and klib.default_config().lk_sums == klib.LK_SUMS_TREE   # the tests' reading; the library's default
     _lk_identical(*ctx.pyrlk(0, 1, pts), *oracle.pyrlk(a, b, pts, nthreads=8, sums=oracle.SUMS_EXACT))
     go, gs, ge, both = _lk_both(ctx, oracle, klib, a, b, pts)
     inner = both & (pts[:, 0] > 40) & (pts[:, 0] < W - 40) & (pts[:, 1] > 40) & (pts[:, 1] < H - 40)

@@ -46,7 +46,7 @@ def _run_end_to_end(make_ctx, oracle, W, H, NF, nthreads):
     oracle with OpenCV's serial float accumulators, runs alongside: its distance from the exact-sum oracle is the
     reference's own sensitivity to the rounding of those sums.  Returns the trajectories and counters."""
     scene, ctx, otr = _pair(make_ctx, oracle, W, H, 0x5EED0001, nthreads)
-    assert ctx.cfg.lk_sums == 2 and ctx.cfg.p3p_polish == 0          # the library's defaults
+    assert ctx.cfg.lk_sums == 2 and ctx.cfg.p3p_polish == 0   # exact sums (make_ctx asks for them); closed-form P3P roots, the library's default
     ser = oracle.Tracker(otr.cfg)
     out = dict(g=[], o=[], s=[], gt=[], kf=0, identical=0, same_model=0, frames=0, scene=scene)
     Tgt = np.eye(4)

@@ -2,7 +2,7 @@
 """The frame-pair stream's whole step (detect on the first frames, build all pyramids, track the detected corners) in
 its arrangements, on the benchmark's shape with fewer pairs if asked; run on a GPU box, alone for wall times or under
 `rocprofv3 --kernel-trace` for the kernels' timeline (tools/trace_timeline.py reads its CSV).
-usage: time_stream_step.py [pairs_per_sequence=127] [reps=10] [arrangement: turn|side|one|both|pair]
+usage: time_stream_step.py [pairs_per_sequence=127] [reps=10] [arrangement: turn|side|one|both|pair] [sums: exact|tree, default the library's]
 (one: ktlvo_detect_build_track_dev; both: the three single-context arrangements in turn)
 (pair: the side-by-side step on two contexts in turn, each with its own frames and arrays)"""
 import os
@@ -30,7 +30,7 @@ prev = [q * (P + 1) + i for q in range(Q) for i in range(P)]
 nxt = [s + 1 for s in prev]
 ctx.upload_images(slots, np.stack(frames))
 gp = K.gftt_params(NF, 0.01, 10.0, 3, 0, 0.0)
-lk = K.lk_params()
+lk = K.lk_params(sums={"exact": K.LK_SUMS_EXACT, "tree": K.LK_SUMS_TREE}.get(sys.argv[4] if len(sys.argv) > 4 else "", K.LK_SUMS_DEFAULT))
 dev = torch.device("cuda", 0)
 d_xy = torch.zeros((NP, NF, 2), device=dev); d_r = torch.zeros((NP, NF), device=dev)
 d_c = torch.zeros(NP, dtype=torch.int32, device=dev)
